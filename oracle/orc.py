@@ -1,0 +1,302 @@
+"""ctypes/numpy front end of the CPU oracle (oracle/uvrt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product.  Scene loading (GLB, route XML) is restated here in
+numpy/stdlib; the arithmetic lives in the C file.  Reference citations are file:line relative
+to the reference checkout.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import struct
+import subprocess
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RAY_DT = np.dtype([("dirx", "<f4"), ("diry", "<f4"), ("dirz", "<f4"),
+                   ("origx", "<f4"), ("origy", "<f4"), ("origz", "<f4"),
+                   ("dist", "<f4"), ("triID", "<u4")])                    # cl/tools.cl:8-14
+NODE_DT = np.dtype([("minx", "<f4"), ("miny", "<f4"), ("minz", "<f4"), ("leftFirst", "<i4"),
+                    ("maxx", "<f4"), ("maxy", "<f4"), ("maxz", "<f4"), ("triCount", "<i4")])
+assert RAY_DT.itemsize == 32 and NODE_DT.itemsize == 32
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("aabb_tests", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("max_stack", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def build():
+    """Compile liboracle.so (and the gfx950 build of the reference .cl files when the
+    reference checkout is present)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if os.path.isdir("/root/reference/cl"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        fp = C.POINTER(C.c_float)
+        L.orc_wang_hash.restype = C.c_uint32
+        L.orc_wang_hash.argtypes = [C.c_uint32]
+        L.orc_seed_of.restype = C.c_uint32
+        L.orc_seed_of.argtypes = [C.c_int32, fp, C.c_uint32]
+        L.orc_generate_one.restype = C.c_uint32
+        L.orc_generate_one.argtypes = [C.c_void_p, C.c_int32, fp, C.c_float, C.c_uint32]
+        L.orc_generate.restype = None
+        L.orc_generate.argtypes = [C.c_void_p, C.c_int64, C.c_int64, fp, C.c_float,
+                                   C.POINTER(C.c_uint32)]
+        L.orc_extend.restype = None
+        L.orc_extend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                 C.c_void_p, C.POINTER(Stats), C.c_int]
+        L.orc_accumulate.restype = None
+        L.orc_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32]
+        L.orc_reset.restype = None
+        L.orc_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                C.c_int32]
+        L.orc_compute_dosage.restype = None
+        L.orc_compute_dosage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_float, C.c_int32]
+        L.orc_dosage_to_color.restype = None
+        L.orc_dosage_to_color.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                          C.c_int32]
+        L.orc_floor_height.restype = C.c_float
+        L.orc_floor_height.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_bvh_build.restype = C.c_int32
+        L.orc_bvh_build.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+# --------------------------------------------------------------------------- scene loading
+
+def load_glb(path):
+    """mesh.cpp:5-71: binary glTF, meshes[0].primitives[0] only, POSITION + u16/u32 indices,
+    no node transforms, no byteStride.  Returns float32 [T,16] in the 64-byte Tri layout
+    (mesh.h:6-13); pads and centroid are zero (the reference leaves them uninitialised)."""
+    b = open(path, "rb").read()
+    magic, _ver, _length = struct.unpack_from("<4sII", b, 0)
+    if magic != b"glTF":
+        raise ValueError("not a GLB file")
+    clen, ctype = struct.unpack_from("<I4s", b, 12)
+    if ctype != b"JSON":
+        raise ValueError("first chunk is not JSON")
+    doc = json.loads(b[20:20 + clen])
+    off = 20 + clen
+    blen, btype = struct.unpack_from("<I4s", b, off)
+    if btype != b"BIN\x00":
+        raise ValueError("second chunk is not BIN")
+    binbuf = b[off + 8: off + 8 + blen]
+    prim = doc["meshes"][0]["primitives"][0]
+    pacc = doc["accessors"][prim["attributes"]["POSITION"]]
+    iacc = doc["accessors"][prim["indices"]]
+    pview = doc["bufferViews"][pacc["bufferView"]]
+    iview = doc["bufferViews"][iacc["bufferView"]]
+    poff = pview.get("byteOffset", 0) + pacc.get("byteOffset", 0)
+    ioff = iview.get("byteOffset", 0) + iacc.get("byteOffset", 0)
+    pos = np.frombuffer(binbuf, dtype="<f4", count=pacc["count"] * 3, offset=poff).reshape(-1, 3)
+    if iacc["componentType"] == 5123:
+        idx = np.frombuffer(binbuf, dtype="<u2", count=iacc["count"], offset=ioff)
+    elif iacc["componentType"] == 5125:
+        idx = np.frombuffer(binbuf, dtype="<u4", count=iacc["count"], offset=ioff)
+    else:
+        raise ValueError("indices must be u16 or u32 (mesh.cpp:44-51)")
+    T = iacc["count"] // 3
+    idx = idx[:T * 3].astype(np.int64).reshape(T, 3)
+    tris = np.zeros((T, 16), dtype=np.float32)
+    tris[:, 0:3] = pos[idx[:, 0]]
+    tris[:, 4:7] = pos[idx[:, 1]]
+    tris[:, 8:11] = pos[idx[:, 2]]
+    return np.ascontiguousarray(tris)
+
+
+def floor_height(tris):
+    """mesh.cpp:100-136 over the duplicated vertex list (3 vertices per triangle)."""
+    y = np.ascontiguousarray(tris[:, [1, 5, 9]].reshape(-1))
+    return float(lib().orc_floor_height(_p(y), y.size))
+
+
+def build_bvh(tris):
+    """bvh.cpp:5-44.  Mutates tris[:,12:15] (centroids).  Returns (nodes[extent], triIdx)."""
+    T = tris.shape[0]
+    cap = 2 * T + 64
+    nodes = np.zeros(cap, dtype=NODE_DT)
+    triIdx = np.zeros(T, dtype=np.uint32)
+    ext = lib().orc_bvh_build(_p(tris), T, _p(nodes), cap, _p(triIdx))
+    if ext < 0:
+        raise RuntimeError("orc_bvh_build failed")
+    return nodes[:ext].copy(), triIdx
+
+
+def load_route(path):
+    """raytracer.cpp:261-300 (Dutch tags).  Missing tags keep the class defaults of
+    raytracer.h:28-37."""
+    r = {"photonCount": 1 << 25, "maxIterations": 10, "lightIntensity": 450.0,
+         "minDosage": 100.0, "minPower": 1500.0, "lightLength": 1.0, "lightHeight": 0.8,
+         "lamps": []}
+    root = ET.parse(path).getroot()
+    tag = {"aantal_fotonen": ("photonCount", int), "aantal_iteraties": ("maxIterations", int),
+           "lamp_sterkte": ("lightIntensity", float), "minimale_dosis": ("minDosage", float),
+           "minimale_bestralingssterkte": ("minPower", float),
+           "lamp_lengte": ("lightLength", float), "lamp_hoogte": ("lightHeight", float)}
+    for k, (name, conv) in tag.items():
+        e = root.find(k)
+        if e is not None and e.text is not None:
+            r[name] = conv(e.text)
+    route = root.find("route")
+    if route is not None:
+        i = 0
+        while True:
+            e = route.find("lamp_positie_%d" % i)
+            if e is None:
+                break
+            r["lamps"].append((float(e.get("positie_x")), float(e.get("positie_y")),
+                               float(e.get("duration"))))
+            i += 1
+    for k in ("lightIntensity", "minDosage", "minPower", "lightLength", "lightHeight"):
+        r[k] = float(np.float32(r[k]))
+    return r
+
+
+# ------------------------------------------------------------------------------- kernels
+
+def seed_of(tid, lp, SEED):
+    return int(lib().orc_seed_of(int(tid), _f3(lp), int(SEED)))
+
+
+def generate(first, n, lp, lightLength, SEED):
+    """Returns (rays[n], SEED_k)."""
+    rays = np.zeros(n, dtype=RAY_DT)
+    s = C.c_uint32(int(SEED))
+    lib().orc_generate(_p(rays), int(first), int(n), _f3(lp), float(np.float32(lightLength)),
+                       C.byref(s))
+    return rays, int(s.value)
+
+
+def extend(temp, tris, rays, nodes, triIdx, nthreads=0):
+    st = Stats()
+    lib().orc_extend(_p(temp), _p(tris), _p(rays), rays.size, _p(nodes), _p(triIdx),
+                     C.byref(st), int(nthreads))
+    return st.as_dict()
+
+
+def accumulate(photonMap, maxPhotonMap, temp, timeStep):
+    lib().orc_accumulate(_p(photonMap), _p(maxPhotonMap), _p(temp),
+                         float(np.float32(timeStep)), temp.size)
+
+
+def reset(photonMap, maxPhotonMap, temp, color=None):
+    lib().orc_reset(_p(photonMap), _p(maxPhotonMap), _p(temp),
+                    _p(color) if color is not None else None, 0 if color is None else 1,
+                    temp.size)
+
+
+def compute_dosage(pmap, tris, photonsPerLight, scaledPower):
+    dose = np.zeros(pmap.size, dtype=np.float32)
+    lib().orc_compute_dosage(_p(pmap), _p(dose), _p(tris), int(photonsPerLight),
+                             float(np.float32(scaledPower)), pmap.size)
+    return dose
+
+
+def dosage_to_color(dose, minValue, thresholdView):
+    color = np.zeros((dose.size, 9), dtype=np.float32)
+    lib().orc_dosage_to_color(_p(dose), _p(color), float(np.float32(minValue)),
+                              int(bool(thresholdView)), dose.size)
+    return color
+
+
+def algorithmic_bytes_per_ray(st):
+    """B_extend = 32 + 8 + 32*(1+A) + (4+64)*K + 4*H with the reference record
+    sizes (32-B ray, 32-B node, 64-B triangle, 4-B index)."""
+    n = float(st["rays"])
+    A = st["aabb_tests"] / n
+    K = st["tri_tests"] / n
+    H = st["hits"] / n
+    return 32.0 + 8.0 + 32.0 * (1.0 + A) + 68.0 * K + 4.0 * H
+
+
+class Scene:
+    """What MyApp::Init hands to RayTracer::Init (myapp.cpp:36-39): Tri[], floorHeight, BVH."""
+
+    def __init__(self, glb_path):
+        self.tris = load_glb(glb_path)
+        self.T = self.tris.shape[0]
+        self.floorHeight = floor_height(self.tris)
+        self.nodes, self.triIdx = build_bvh(self.tris)
+
+
+class Computation:
+    """Host sequence of raytracer.cpp:66-143 + myapp.cpp:156-175 on the oracle kernels."""
+
+    def __init__(self, scene, lamps, photonCount, lightHeight, lightLength, lightIntensity,
+                 nthreads=0):
+        self.s = scene
+        self.lamps = list(lamps)
+        self.photonCount = int(photonCount)
+        self.photonsPerLight = (self.photonCount // len(self.lamps)) & ~1   # raytracer.cpp:63
+        self.lightHeight = np.float32(lightHeight)
+        self.lightLength = np.float32(lightLength)
+        self.lightIntensity = np.float32(lightIntensity)
+        self.nthreads = nthreads
+        T = scene.T
+        self.photonMap = np.zeros(T, dtype=np.float64)
+        self.maxPhotonMap = np.zeros(T, dtype=np.float64)
+        self.temp = np.zeros(T, dtype=np.int32)
+        self.SEED = 0                      # fresh Init: program-scope SEED is zero
+        self.photonMapSize = 0
+        self.stats = []
+        self.last_rays = None
+
+    def lamp_world_pos(self, lamp):
+        # raytracer.cpp:77 -- f32 add
+        y = np.float32(np.float32(self.s.floorHeight) + self.lightHeight)
+        return (np.float32(lamp[0]), y, np.float32(lamp[1]))
+
+    def reset(self):                                       # raytracer.cpp:122-143
+        self.photonMapSize = 0
+        reset(self.photonMap, self.maxPhotonMap, self.temp)
+
+    def single_light(self, lamp, first=0, n=None):         # raytracer.cpp:75-88
+        n = self.photonsPerLight if n is None else n
+        lp = self.lamp_world_pos(lamp)
+        rays, self.SEED = generate(first, n, lp, self.lightLength, self.SEED)
+        st = extend(self.temp, self.s.tris, rays, self.s.nodes, self.s.triIdx, self.nthreads)
+        self.stats.append(st)
+        self.last_rays = rays
+        accumulate(self.photonMap, self.maxPhotonMap, self.temp, lamp[2])
+        self.photonMapSize += n
+
+    def iteration(self):                                   # raytracer.cpp:66-72
+        for lamp in self.lamps:
+            self.single_light(lamp)
+
+    def dose(self):                                        # raytracer.cpp:106-118
+        return compute_dosage(self.photonMap, self.s.tris,
+                              self.photonMapSize // len(self.lamps),
+                              np.float32(self.lightIntensity * np.float32(0.1)))
+
+    def max_power(self):                                   # raytracer.cpp:96-104
+        return compute_dosage(self.maxPhotonMap, self.s.tris, self.photonsPerLight,
+                              np.float32(self.lightIntensity * np.float32(100.0)))

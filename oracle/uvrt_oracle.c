@@ -1,0 +1,534 @@
+/*
+ * uvrt_oracle.c -- CPU restatement of the reference UV-dose hot path (see uvrt_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY: the checker for the HIP path and the timed CPU baseline.
+ * Build with: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
+ * x86-64 SSE2 scalar arithmetic is IEEE binary32/binary64 with no excess precision, so each
+ * C operator below is exactly one rounding, in the order the reference source writes it.
+ */
+#include "uvrt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------- RNG: cl/tools.cl:2-4 */
+
+uint32_t orc_wang_hash(uint32_t s)
+{
+    s = (s ^ 61u) ^ (s >> 16);
+    s *= 9u;
+    s = s ^ (s >> 4);
+    s *= 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    return s;
+}
+
+uint32_t orc_random_int(uint32_t* s)
+{
+    *s ^= *s << 13;
+    *s ^= *s >> 17;
+    *s ^= *s << 5;
+    return *s;
+}
+
+float orc_random_float(uint32_t* s)
+{
+    /* uint -> float (round to nearest even), then one f32 multiply by 2^-32 */
+    return (float)orc_random_int(s) * 2.3283064365387e-10f;
+}
+
+/* ------------------------------------------------------------ generate: cl/generate.cl */
+
+/* cl/generate.cl:13.  C usual-arithmetic conversions give
+ *   ((((float)(tid*17+1) + lp.x*13.0f) + lp.y*7.0f) + lp.z*11.0f) + (float)(SEED>>15)
+ * followed by an implicit float->uint conversion, taken through int64 (SURVEY.md 8a/8c:
+ * what the x86-64 build of the reference kernel does; negative sums wrap modulo 2^32). */
+uint32_t orc_seed_of(int32_t tid, const float lp[3], uint32_t SEED)
+{
+    float acc = (float)(tid * 17 + 1);
+    acc = acc + lp[0] * 13.0f;
+    acc = acc + lp[1] * 7.0f;
+    acc = acc + lp[2] * 11.0f;
+    acc = acc + (float)(SEED >> 15);
+    return (uint32_t)(int64_t)acc;
+}
+
+uint32_t orc_generate_one(orc_ray* out, int32_t tid, const float lp[3], float lightLength,
+                          uint32_t SEED)
+{
+    uint32_t seed = orc_wang_hash(orc_seed_of(tid, lp, SEED));          /* :13 */
+
+    out->origx = lp[0];                                                  /* :16-19 */
+    out->origy = lp[1] + orc_random_float(&seed) * lightLength;
+    out->origz = lp[2];
+
+    float diry = orc_random_float(&seed) * 2.0f - 1.0f;                  /* :22 */
+    double dirxzlength = sqrt(1.0 - (double)diry * (double)diry);        /* :23 */
+
+    /* :25 -- vector literal elements are evaluated left to right */
+    double x = (double)(orc_random_float(&seed) * 2.0f - 1.0f);
+    double y = (double)(orc_random_float(&seed) * 2.0f - 1.0f);
+    while (x * x + y * y > 1.0) {                                        /* :26-28 */
+        x = (double)(orc_random_float(&seed) * 2.0f - 1.0f);
+        y = (double)(orc_random_float(&seed) * 2.0f - 1.0f);
+    }
+    double s = dirxzlength / sqrt(x * x + y * y);                        /* :29 */
+    x = x * s;
+    y = y * s;
+
+    out->dirx = (float)x;                                                /* :31-35 */
+    out->diry = diry;
+    out->dirz = (float)y;
+    out->dist = 1e30f;
+    out->triID = 0;
+    return seed;                                                         /* :39 (tid 0) */
+}
+
+void orc_generate(orc_ray* rays, int64_t first, int64_t n, const float lp[3],
+                  float lightLength, uint32_t* SEED)
+{
+    /* SEED_k = final RNG state of work-item 0, which itself read SEED_{k-1} */
+    orc_ray scratch;
+    const uint32_t seed_prev = *SEED;
+    const uint32_t seed_next = orc_generate_one(&scratch, 0, lp, lightLength, seed_prev);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t gid = first + i;
+        orc_generate_one(&rays[i], (int32_t)gid, lp, lightLength,
+                         gid == 0 ? seed_prev : seed_next);
+    }
+    *SEED = seed_next;
+}
+
+/* ---------------------------------------------------------------- extend: cl/extend.cl */
+
+static inline float cl_minf(float x, float y) { return y < x ? y : x; }
+static inline float cl_maxf(float x, float y) { return x < y ? y : x; }
+
+/* cl/extend.cl:6-27 */
+static inline void intersect_tri(orc_ray* ray, const orc_tri* tri, uint32_t triID)
+{
+    const float e1x = tri->v1x - tri->v0x, e1y = tri->v1y - tri->v0y, e1z = tri->v1z - tri->v0z;
+    const float e2x = tri->v2x - tri->v0x, e2y = tri->v2y - tri->v0y, e2z = tri->v2z - tri->v0z;
+    /* h = cross(dir, edge2) */
+    const float hx = ray->diry * e2z - ray->dirz * e2y;
+    const float hy = ray->dirz * e2x - ray->dirx * e2z;
+    const float hz = ray->dirx * e2y - ray->diry * e2x;
+    const float a = e1x * hx + e1y * hy + e1z * hz;
+    if (fabsf(a) < 0.00001f) return;
+    const float f = 1.0f / a;
+    const float sx = ray->origx - tri->v0x, sy = ray->origy - tri->v0y, sz = ray->origz - tri->v0z;
+    const float u = f * (sx * hx + sy * hy + sz * hz);
+    if ((u < 0) | (u > 1)) return;
+    /* q = cross(s, edge1) */
+    const float qx = sy * e1z - sz * e1y;
+    const float qy = sz * e1x - sx * e1z;
+    const float qz = sx * e1y - sy * e1x;
+    const float v = f * (ray->dirx * qx + ray->diry * qy + ray->dirz * qz);
+    if ((v < 0) | (u + v > 1)) return;
+    const float t = f * (e2x * qx + e2y * qy + e2z * qz);
+    if (t > 0.0001f && t < ray->dist) {
+        ray->dist = t;
+        ray->triID = triID;
+    }
+}
+
+/* cl/extend.cl:29-38 */
+static inline float intersect_aabb(const orc_ray* ray, const orc_node* node)
+{
+    float tx1 = (node->minx - ray->origx) / ray->dirx, tx2 = (node->maxx - ray->origx) / ray->dirx;
+    float tmin = cl_minf(tx1, tx2), tmax = cl_maxf(tx1, tx2);
+    float ty1 = (node->miny - ray->origy) / ray->diry, ty2 = (node->maxy - ray->origy) / ray->diry;
+    tmin = cl_maxf(tmin, cl_minf(ty1, ty2)), tmax = cl_minf(tmax, cl_maxf(ty1, ty2));
+    float tz1 = (node->minz - ray->origz) / ray->dirz, tz2 = (node->maxz - ray->origz) / ray->dirz;
+    tmin = cl_maxf(tmin, cl_minf(tz1, tz2)), tmax = cl_minf(tmax, cl_maxf(tz1, tz2));
+    if (tmax >= tmin && tmin < ray->dist && tmax > 0) return tmin; else return 1e30f;
+}
+
+/* cl/extend.cl:40-81 */
+static inline void bvh_intersect(orc_ray* ray, const orc_tri* tri, const orc_node* bvhNode,
+                                 const uint32_t* triIdx, orc_stats* st)
+{
+    const orc_node* node = &bvhNode[0];
+    const orc_node* stack[32];
+    uint32_t stackPtr = 0;
+    while (1) {
+        st->node_visits++;
+        if (node->triCount > 0) {
+            for (uint32_t i = 0; i < (uint32_t)node->triCount; i++) {
+                uint32_t triID = triIdx[node->leftFirst + i];
+                st->tri_tests++;
+                intersect_tri(ray, &tri[triID], triID);
+            }
+            if (stackPtr == 0) break; else node = stack[--stackPtr];
+            continue;
+        }
+        const orc_node* child1 = &bvhNode[node->leftFirst];
+        const orc_node* child2 = &bvhNode[node->leftFirst + 1];
+        float dist1 = intersect_aabb(ray, child1);
+        float dist2 = intersect_aabb(ray, child2);
+        st->aabb_tests += 2;
+        if (dist1 > dist2) {
+            float d = dist1; dist1 = dist2; dist2 = d;
+            const orc_node* c = child1; child1 = child2; child2 = c;
+        }
+        if (dist1 == 1e30f) {
+            if (stackPtr == 0) break; else node = stack[--stackPtr];
+        } else {
+            node = child1;
+            if (dist2 != 1e30f) {
+                stack[stackPtr++] = child2;
+                if (stackPtr > st->max_stack) st->max_stack = stackPtr;
+            }
+        }
+    }
+}
+
+void orc_extend(int32_t* tempPhotonMap, const orc_tri* tris, orc_ray* rays, int64_t n,
+                const orc_node* nodes, const uint32_t* triIdx, orc_stats* stats, int nthreads)
+{
+    orc_stats total;
+    memset(&total, 0, sizeof total);
+    total.rays = (uint64_t)n;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads)
+    {
+        orc_stats st;
+        memset(&st, 0, sizeof st);
+#pragma omp for schedule(dynamic, 4096)
+        for (int64_t i = 0; i < n; i++) {
+            orc_ray* r = &rays[i];
+            bvh_intersect(r, tris, nodes, triIdx, &st);
+            if (r->dist != 1e30f) {                                      /* :94-98 */
+                st.hits++;
+                __atomic_fetch_add(&tempPhotonMap[r->triID], 1, __ATOMIC_RELAXED);
+            }
+        }
+#pragma omp critical
+        {
+            total.node_visits += st.node_visits;
+            total.aabb_tests += st.aabb_tests;
+            total.tri_tests += st.tri_tests;
+            total.hits += st.hits;
+            if (st.max_stack > total.max_stack) total.max_stack = st.max_stack;
+        }
+    }
+    if (stats) *stats = total;
+}
+
+/* ------------------------------------------------- accumulate / reset / shade kernels */
+
+void orc_accumulate(double* photonMap, double* maxPhotonMap, int32_t* temp, float timeStep,
+                    int32_t T)
+{
+    for (int32_t i = 0; i < T; i++) {
+        photonMap[i] = photonMap[i] + (double)temp[i] * (double)timeStep;   /* :9 */
+        double c = (double)temp[i];
+        maxPhotonMap[i] = maxPhotonMap[i] < c ? c : maxPhotonMap[i];        /* :11 */
+        temp[i] = 0;                                                        /* :13 */
+    }
+}
+
+void orc_reset(double* photonMap, double* maxPhotonMap, int32_t* temp, orc_tricolor* colorMap,
+               int32_t resetColor, int32_t T)
+{
+    for (int32_t i = 0; i < T; i++) {
+        photonMap[i] = 0;
+        maxPhotonMap[i] = 0;
+        temp[i] = 0;
+        if (!resetColor) continue;
+        memset(&colorMap[i], 0, sizeof(orc_tricolor));     /* (float)0.0 nine times, :15-25 */
+    }
+}
+
+void orc_compute_dosage(const double* photonMap, float* dosageMap, const orc_tri* tris,
+                        int32_t photonsPerLight, float scaledPower, int32_t T)
+{
+    for (int32_t i = 0; i < T; i++) {
+        const orc_tri* t = &tris[i];
+        /* :33-36 */
+        float ax = t->v0x - t->v1x, ay = t->v0y - t->v1y, az = t->v0z - t->v1z;
+        float bx = t->v0x - t->v2x, by = t->v0y - t->v2y, bz = t->v0z - t->v2z;
+        float cx = ay * bz - az * by;
+        float cy = az * bx - ax * bz;
+        float cz = ax * by - ay * bx;
+        float area = sqrtf(cx * cx + cy * cy + cz * cz) / 2.0f;
+        /* :39 -- f32*f64 -> f64 ; f32*(int->f32) -> f32 ; f64/f32 -> f64 ; narrowed to f32 */
+        float dose = (float)(((double)scaledPower * photonMap[i]) /
+                             (double)(area * (float)photonsPerLight));
+        dosageMap[i] = dose;
+    }
+}
+
+/* cl/shade.cl:4-21 */
+static void heatmap(float intensity, float rgb[3])
+{
+    float minDosageColor = 0.5f;
+    float upperHalfColor = (float)((double)minDosageColor + (1.0 - (double)minDosageColor) / 2);
+    float lowerHalfColor = minDosageColor / 2.0f;
+    if (intensity > minDosageColor) {
+        if (intensity > upperHalfColor) {
+            rgb[0] = 1.0f; rgb[1] = (1.0f - intensity) / (1.0f - upperHalfColor); rgb[2] = 0;
+        } else {
+            rgb[0] = (intensity - minDosageColor) / (upperHalfColor - minDosageColor);
+            rgb[1] = 1.0f; rgb[2] = 0;
+        }
+    } else {
+        if (intensity > lowerHalfColor) {
+            rgb[0] = 0; rgb[1] = 1.0f;
+            rgb[2] = (minDosageColor - intensity) / (minDosageColor - lowerHalfColor);
+        } else {
+            rgb[0] = 0; rgb[1] = intensity / lowerHalfColor; rgb[2] = 1.0f;
+        }
+    }
+}
+
+void orc_dosage_to_color(const float* dosageMap, orc_tricolor* colorMap, float minValue,
+                         int32_t thresholdView, int32_t T)
+{
+    for (int32_t i = 0; i < T; i++) {
+        float maxValue = minValue * 2;                                    /* :49 */
+        float normValue = dosageMap[i] / maxValue;                        /* :51 */
+        float c[3];
+        if (thresholdView && normValue < 0.5f) {                          /* :56-57 */
+            c[0] = 0; c[1] = 0; c[2] = normValue * 2.0f;
+        } else {
+            heatmap(normValue, c);
+        }
+        orc_tricolor* tc = &colorMap[i];
+        tc->v0x = c[0]; tc->v0y = c[1]; tc->v0z = c[2];
+        tc->v1x = c[0]; tc->v1y = c[1]; tc->v1z = c[2];
+        tc->v2x = c[0]; tc->v2y = c[1]; tc->v2z = c[2];
+    }
+}
+
+/* ------------------------------------------------------- floor height: mesh.cpp:100-136 */
+
+float orc_floor_height(const float* yvals, int32_t count)
+{
+    enum { binCount = 48 };
+    float maxVal = 0.0f, minVal = 0.0f;
+    int hist[binCount];
+    for (int j = 0; j < binCount; ++j) hist[j] = 0;
+    for (int32_t i = 0; i < count; ++i)
+        if (yvals[i] < minVal) minVal = yvals[i];
+    float range = maxVal - minVal;
+    for (int32_t i = 0; i < count; ++i) {
+        float y = yvals[i];
+        for (int j = 0; j < binCount; ++j) {
+            /* :120 -- int*float -> float, / int -> float, + float */
+            if ((float)j * range / (float)binCount + minVal < y &&
+                y < (float)(j + 1) * range / (float)binCount + minVal)
+                hist[j]++;
+        }
+    }
+    int maxCount = 0, maxIndex = -1;
+    for (int i = 0; i < binCount; ++i)
+        if (hist[i] > maxCount) { maxIndex = i; maxCount = hist[i]; }
+    return ((float)maxIndex + 0.5f) * range / (float)binCount + minVal;   /* :135 */
+}
+
+/* ------------------------------------------------------------------ BVH: bvh.cpp:5-220 */
+
+#define ORC_BINS 8
+
+typedef struct {
+    orc_tri* tris;
+    int32_t T;
+    orc_node* nodes;
+    int32_t cap;
+    uint32_t* triIdx;
+    int32_t extent;           /* highest written node index + 1 */
+    int overflow;
+    struct { uint32_t nodeIdx; float cmin[3], cmax[3]; } job[64];
+    int njobs;
+} bvh_ctx;
+
+/* _mm_min_ps(a,b) / _mm_max_ps(a,b) lane semantics */
+static inline float sse_min(float a, float b) { return a < b ? a : b; }
+static inline float sse_max(float a, float b) { return a > b ? a : b; }
+
+static inline const float* tri_vert(const orc_tri* t, int k) { return &t->v0x + 4 * k; }
+static inline const float* tri_centroid(const orc_tri* t) { return &t->cx; }
+
+/* bvh.cpp:181-200 (USE_SSE path): vertex AABB into the node, centroid bounds by reference */
+static void update_node_bounds(bvh_ctx* c, uint32_t nodeIdx, float cmin[3], float cmax[3])
+{
+    orc_node* node = &c->nodes[nodeIdx];
+    float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+    float cn[3] = {1e30f, 1e30f, 1e30f}, cx[3] = {-1e30f, -1e30f, -1e30f};
+    uint32_t first = (uint32_t)node->leftFirst;
+    for (uint32_t i = 0; i < (uint32_t)node->triCount; i++) {
+        const orc_tri* t = &c->tris[c->triIdx[first + i]];
+        for (int k = 0; k < 3; k++) {
+            const float* v = tri_vert(t, k);
+            for (int a = 0; a < 3; a++) {
+                mn[a] = sse_min(mn[a], v[a]);
+                mx[a] = sse_max(mx[a], v[a]);
+            }
+        }
+        const float* ce = tri_centroid(t);
+        for (int a = 0; a < 3; a++) {
+            cn[a] = sse_min(cn[a], ce[a]);
+            cx[a] = sse_max(cx[a], ce[a]);
+        }
+    }
+    node->minx = mn[0]; node->miny = mn[1]; node->minz = mn[2];
+    node->maxx = mx[0]; node->maxy = mx[1]; node->maxz = mx[2];
+    for (int a = 0; a < 3; a++) { cmin[a] = cn[a]; cmax[a] = cx[a]; }
+}
+
+/* bvh.cpp:98-179 (USE_SSE path) */
+static float find_best_split(bvh_ctx* c, const orc_node* node, int* axis, int* splitPos,
+                             const float cmin[3], const float cmax[3])
+{
+    float bestCost = 1e30f;
+    for (int a = 0; a < 3; a++) {
+        float boundsMin = cmin[a], boundsMax = cmax[a];
+        if (boundsMin == boundsMax) continue;
+        float scale = (float)ORC_BINS / (boundsMax - boundsMin);
+        float leftCountArea[ORC_BINS - 1], rightCountArea[ORC_BINS - 1];
+        int leftSum = 0, rightSum = 0;
+        float bmin[ORC_BINS][3], bmax[ORC_BINS][3];
+        uint32_t count[ORC_BINS];
+        for (int i = 0; i < ORC_BINS; i++) {
+            for (int k = 0; k < 3; k++) { bmin[i][k] = 1e30f; bmax[i][k] = -1e30f; }
+            count[i] = 0;
+        }
+        for (uint32_t i = 0; i < (uint32_t)node->triCount; i++) {
+            const orc_tri* t = &c->tris[c->triIdx[node->leftFirst + i]];
+            int binIdx = (int)((tri_centroid(t)[a] - boundsMin) * scale);
+            if (binIdx > ORC_BINS - 1) binIdx = ORC_BINS - 1;               /* :119 */
+            count[binIdx]++;
+            for (int k = 0; k < 3; k++) {
+                const float* v = tri_vert(t, k);
+                for (int d = 0; d < 3; d++) {
+                    bmin[binIdx][d] = sse_min(bmin[binIdx][d], v[d]);
+                    bmax[binIdx][d] = sse_max(bmax[binIdx][d], v[d]);
+                }
+            }
+        }
+        /* :129-143.  NOTE the reference sweeps the right COUNT over bins 7-i but the right
+         * BOX over bins 6-i (index BINS-2-i): restated as written, not as intended. */
+        float lmin[3] = {1e30f, 1e30f, 1e30f}, rmin[3] = {1e30f, 1e30f, 1e30f};
+        float lmax[3] = {-1e30f, -1e30f, -1e30f}, rmax[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = 0; i < ORC_BINS - 1; i++) {
+            leftSum += (int)count[i];
+            rightSum += (int)count[ORC_BINS - 1 - i];
+            float le[3], re[3];
+            for (int d = 0; d < 3; d++) {
+                lmin[d] = sse_min(lmin[d], bmin[i][d]);
+                rmin[d] = sse_min(rmin[d], bmin[ORC_BINS - 2 - i][d]);
+                lmax[d] = sse_max(lmax[d], bmax[i][d]);
+                rmax[d] = sse_max(rmax[d], bmax[ORC_BINS - 2 - i][d]);
+                le[d] = lmax[d] - lmin[d];
+                re[d] = rmax[d] - rmin[d];
+            }
+            leftCountArea[i] = (float)leftSum * (le[0] * le[1] + le[1] * le[2] + le[2] * le[0]);
+            rightCountArea[ORC_BINS - 2 - i] =
+                (float)rightSum * (re[0] * re[1] + re[1] * re[2] + re[2] * re[0]);
+        }
+        for (int i = 0; i < ORC_BINS - 1; i++) {                           /* :171-176 */
+            const float planeCost = leftCountArea[i] + rightCountArea[i];
+            if (planeCost < bestCost) { *axis = a; *splitPos = i + 1; bestCost = planeCost; }
+        }
+    }
+    return bestCost;
+}
+
+static void touch(bvh_ctx* c, uint32_t idx)
+{
+    if ((int32_t)idx + 1 > c->extent) c->extent = (int32_t)idx + 1;
+}
+
+/* bvh.cpp:46-96 */
+static void subdivide(bvh_ctx* c, uint32_t nodeIdx, uint32_t depth, uint32_t* nodePtr,
+                      float cmin[3], float cmax[3])
+{
+    orc_node* node = &c->nodes[nodeIdx];
+    int axis = 0, splitPos = 0;
+    float splitCost = find_best_split(c, node, &axis, &splitPos, cmin, cmax);
+    /* bvh.h:16-20 CalculateNodeCost */
+    float ex = node->maxx - node->minx, ey = node->maxy - node->miny, ez = node->maxz - node->minz;
+    float nosplitCost = (ex * ey + ey * ez + ez * ex) * (float)(uint32_t)node->triCount;
+    if (splitCost >= nosplitCost) return;
+    int i = node->leftFirst;
+    int j = i + node->triCount - 1;
+    float scale = (float)ORC_BINS / (cmax[axis] - cmin[axis]);
+    while (i <= j) {
+        int binIdx = (int)((tri_centroid(&c->tris[c->triIdx[i]])[axis] - cmin[axis]) * scale);
+        if (binIdx > ORC_BINS - 1) binIdx = ORC_BINS - 1;
+        if (binIdx < splitPos) i++;
+        else { uint32_t t = c->triIdx[i]; c->triIdx[i] = c->triIdx[j]; c->triIdx[j] = t; j--; }
+    }
+    int leftCount = i - node->leftFirst;
+    if (leftCount == 0 || leftCount == node->triCount) return;
+    if ((int32_t)(*nodePtr) + 2 > c->cap) { c->overflow = 1; return; }
+    uint32_t leftChildIdx = (*nodePtr)++;
+    uint32_t rightChildIdx = (*nodePtr)++;
+    touch(c, rightChildIdx);
+    c->nodes[leftChildIdx].leftFirst = node->leftFirst;
+    c->nodes[leftChildIdx].triCount = leftCount;
+    c->nodes[rightChildIdx].leftFirst = i;
+    c->nodes[rightChildIdx].triCount = node->triCount - leftCount;
+    node->leftFirst = (int32_t)leftChildIdx;
+    node->triCount = 0;
+    update_node_bounds(c, leftChildIdx, cmin, cmax);
+    if (depth == 3) {
+        c->job[c->njobs].nodeIdx = leftChildIdx;
+        memcpy(c->job[c->njobs].cmin, cmin, sizeof(float) * 3);
+        memcpy(c->job[c->njobs].cmax, cmax, sizeof(float) * 3);
+        c->njobs++;
+    } else subdivide(c, leftChildIdx, depth + 1, nodePtr, cmin, cmax);
+    update_node_bounds(c, rightChildIdx, cmin, cmax);
+    if (depth == 3) {
+        c->job[c->njobs].nodeIdx = rightChildIdx;
+        memcpy(c->job[c->njobs].cmin, cmin, sizeof(float) * 3);
+        memcpy(c->job[c->njobs].cmax, cmax, sizeof(float) * 3);
+        c->njobs++;
+    } else subdivide(c, rightChildIdx, depth + 1, nodePtr, cmin, cmax);
+}
+
+int32_t orc_bvh_build(orc_tri* tris, int32_t T, orc_node* nodes, int32_t nodes_cap,
+                      uint32_t* triIdx)
+{
+    if (T <= 0 || nodes_cap < 2 * T + 64) return -1;
+    bvh_ctx c;
+    memset(&c, 0, sizeof c);
+    c.tris = tris; c.T = T; c.nodes = nodes; c.cap = nodes_cap; c.triIdx = triIdx;
+    uint32_t nodesUsed = 2;                                               /* :16 */
+    memset(nodes, 0, sizeof(orc_node) * (size_t)nodes_cap);               /* :17 (whole pool) */
+    for (int32_t i = 0; i < T; i++) triIdx[i] = (uint32_t)i;              /* :19 */
+    for (int32_t i = 0; i < T; i++) {                                     /* :23 */
+        orc_tri* t = &tris[i];
+        t->cx = (t->v0x + t->v1x + t->v2x) * 0.3333f;
+        t->cy = (t->v0y + t->v1y + t->v2y) * 0.3333f;
+        t->cz = (t->v0z + t->v1z + t->v2z) * 0.3333f;
+    }
+    nodes[0].leftFirst = 0; nodes[0].triCount = T;                        /* :25-26 */
+    c.extent = 1;
+    float cmin[3], cmax[3];
+    update_node_bounds(&c, 0, cmin, cmax);                                /* :28 */
+    c.njobs = 0;
+    subdivide(&c, 0, 0, &nodesUsed, cmin, cmax);                          /* :31 */
+    uint32_t nodePtr[64];                                                 /* :33-36 */
+    int N = c.njobs;
+    nodePtr[0] = nodesUsed;
+    for (int i = 1; i < N; i++)
+        nodePtr[i] = nodePtr[i - 1] + (uint32_t)nodes[c.job[i - 1].nodeIdx].triCount * 2;
+    for (int i = 0; i < N; i++) {                                         /* :38-42, serial */
+        float jmin[3], jmax[3];
+        memcpy(jmin, c.job[i].cmin, sizeof jmin);
+        memcpy(jmax, c.job[i].cmax, sizeof jmax);
+        subdivide(&c, c.job[i].nodeIdx, 99, &nodePtr[i], jmin, jmax);
+    }
+    if (c.overflow) return -1;
+    return c.extent;
+}
