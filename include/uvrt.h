@@ -1,0 +1,138 @@
+/*
+ * uvrt.h -- C ABI of the MI355X (gfx950) UV-dose hot path.
+ *
+ * This is the drop-in boundary: the entry points below are what the reference's
+ * `RayTracer` (raytracer.h:13-59, raytracer.cpp) needs in place of its OpenCL wrapper
+ * (`Kernel`/`Buffer`, template/precomp.h:1239-1325).  Plain pointers and sizes only; every
+ * call returns UVRT_OK (0) or a negative error code, and uvrt_last_error() returns the text.
+ * A context is bound to one HIP device and one in-order HIP stream (the reference's single
+ * in-order cl_command_queue, template/template.cpp:1446); calls are asynchronous unless they
+ * read back to the host.  Not thread-safe per context (the reference is single-threaded).
+ *
+ * Record layouts handed over by the host are the reference's own:
+ *   Tri      64 B  v0.xyz,pad,v1.xyz,pad,v2.xyz,pad,centroid.xyz,pad   (mesh.h:6-13, cl/tools.cl:31-37)
+ *   BVHNode  32 B  min.xyz,leftFirst,max.xyz,triCount                  (bvh.h:11-21, cl/tools.cl:39-45)
+ *   triIdx   u32[T]                                                    (bvh.h:45)
+ *   Ray      32 B  dir.xyz,orig.xyz,dist,triID                         (cl/tools.cl:8-14)
+ * Inside the context they are re-laid-out for the GPU.
+ */
+#ifndef UVRT_H
+#define UVRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uvrt_ctx uvrt_ctx;
+
+enum {
+    UVRT_OK = 0,
+    UVRT_ERR_INVALID = -1,   /* bad argument / call order */
+    UVRT_ERR_HIP = -2,       /* a HIP runtime call failed */
+    UVRT_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    UVRT_ERR_BVH = -4,       /* malformed BVH (cycle, out-of-range child, leaf beyond triIdx) */
+    UVRT_ERR_STACK = -5      /* traversal needed more than 32 stack entries (extend.cl:43) */
+};
+
+/* which per-triangle map computeDosage reads (raytracer.cpp:96-116) */
+enum { UVRT_MAP_SUM = 0, UVRT_MAP_MAX = 1 };
+
+const char* uvrt_last_error(void);
+const char* uvrt_version(void);
+
+/* Kernel::InitCL + the six `new Kernel(...)` of RayTracer::Init (myapp.cpp:21,
+ * raytracer.cpp:17-22).  A new context starts with SEED = 0, like a freshly built
+ * generate.cl program (generate.cl:6). */
+int uvrt_create(int device_id, uvrt_ctx** out);
+void uvrt_destroy(uvrt_ctx* ctx);
+
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the context's
+ * own.  NULL restores the context's own stream. */
+int uvrt_set_stream(uvrt_ctx* ctx, void* hip_stream);
+
+/* verticesBuffer / bvhNodesBuffer / triIdxBuffer upload (raytracer.cpp:24-30); callable again
+ * at any time (CalibratePower swaps scenes, raytracer.cpp:166-187,212-224).  The arrays are
+ * copied; the caller keeps ownership.  (Re)allocates and zeroes the per-triangle maps
+ * (raytracer.cpp:32-35) when tri_count changes. */
+int uvrt_set_scene(uvrt_ctx* ctx, const void* tris64, int32_t tri_count,
+                   const void* nodes32, int32_t node_count, const uint32_t* tri_idx);
+
+/* rayBuffer = new Buffer(32 * photonCount) (raytracer.cpp:136-139); size_t arithmetic, so the
+ * reference's int overflow at 2^26 photons does not exist here. */
+int uvrt_resize_rays(uvrt_ctx* ctx, int64_t photon_count);
+
+/* cl/reset.cl:4-26 over the current scene's triangles (raytracer.cpp:141-142) */
+int uvrt_reset(uvrt_ctx* ctx, int32_t reset_color);
+
+/* cl/generate.cl:8-40 for global ids [first_gid, first_gid+n) of a launch of any size, under
+ * the pinned SEED semantics of SURVEY.md 8c: work-item 0 reads SEED_{k-1}, every other
+ * work-item reads SEED_k; the context's SEED advances to SEED_k on every call (SEED_k is a
+ * function of light_pos and SEED_{k-1} only, so ranks that generate disjoint gid ranges of the
+ * same launch stay in step).  n <= the capacity set by uvrt_resize_rays. */
+int uvrt_generate(uvrt_ctx* ctx, const float light_pos[3], float light_length,
+                  int64_t first_gid, int64_t n);
+
+/* cl/extend.cl:85-99 over the n rays of the last uvrt_generate: closest hit through the BVH,
+ * then one increment of tempPhotonMap[triID] per hit. */
+int uvrt_extend(uvrt_ctx* ctx, int64_t n);
+
+/* cl/accumulate.cl:4-14 over tri_count triangles */
+int uvrt_accumulate(uvrt_ctx* ctx, float time_step, int32_t tri_count);
+
+/* cl/shade.cl:23-41 (computeDosage) over tri_count triangles */
+int uvrt_compute_dosage(uvrt_ctx* ctx, int32_t which_map, int32_t photons_per_light,
+                        float scaled_power, int32_t tri_count);
+
+/* cl/shade.cl:43-71 (dosageToColor) into the context's 9-float/triangle colour buffer (the
+ * reference writes a GL VBO, raytracer.cpp:37,119) */
+int uvrt_dosage_to_color(uvrt_ctx* ctx, float min_value, int32_t threshold_view,
+                         int32_t tri_count);
+
+/* clFinish(Kernel::GetQueue()) (myapp.cpp:165, raytracer.cpp:202); also reports a traversal
+ * stack overflow raised by any extend since the last sync. */
+int uvrt_sync(uvrt_ctx* ctx);
+
+/* dosageBuffer->CopyFromDevice() (raytracer.cpp:204-207), any range; synchronises. */
+int uvrt_read_dosage(uvrt_ctx* ctx, float* out, int32_t first, int32_t count);
+int uvrt_read_color(uvrt_ctx* ctx, float* out9, int32_t first, int32_t count);
+
+/* ---- program-scope SEED of generate.cl (generate.cl:6,39) ---- */
+int uvrt_get_seed(uvrt_ctx* ctx, uint32_t* seed);
+int uvrt_set_seed(uvrt_ctx* ctx, uint32_t seed);
+/* SEED_k from SEED_{k-1} and the lamp position, without launching (host-side RNG walk of
+ * work-item 0); used to give every rank of a sharded job its place in the global launch
+ * order. */
+uint32_t uvrt_seed_next(const float light_pos[3], float light_length, uint32_t seed_prev);
+
+/* ---- tuning knobs (results never depend on them) ---- */
+/* bits of the ray-coherence key used to order rays before extend; 0 = trace in gid order,
+ * -1 = choose from n (default). */
+int uvrt_set_sort_bits(uvrt_ctx* ctx, int32_t bits);
+/* record (dist, triID) per ray in gid order during extend (the reference updates rays in
+ * place, extend.cl:90-92); off by default, needed by uvrt_read_rays. */
+int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
+/* extend kernel variant: 0 = default; see DESIGN.md */
+int uvrt_set_variant(uvrt_ctx* ctx, int32_t variant);
+
+/* ---- test / interop hooks ---- */
+/* the rays of the last generate (+ extend, if hits were recorded) in the reference's 32-byte
+ * Ray layout and gid order; synchronises. */
+int uvrt_read_rays(uvrt_ctx* ctx, void* rays32, int64_t first, int64_t count);
+int uvrt_read_counts(uvrt_ctx* ctx, int32_t* out, int32_t first, int32_t count);
+int uvrt_read_photon_map(uvrt_ctx* ctx, int32_t which_map, double* out, int32_t first,
+                         int32_t count);
+/* raw device pointers of the per-triangle arrays, for zero-copy wrapping (e.g. as torch
+ * tensors handed to an RCCL collective).  which: 0 photonMap f64[T], 1 maxPhotonMap f64[T],
+ * 2 tempPhotonMap i32[T], 3 dosageMap f32[T], 4 colour f32[9T]. */
+int uvrt_device_ptr(uvrt_ctx* ctx, int32_t which, void** ptr, int64_t* bytes);
+/* time in ms the device spent in the extend kernels since the last call (HIP events on the
+ * context's stream), and the number of extend launches; synchronises. */
+int uvrt_extend_time_ms(uvrt_ctx* ctx, double* ms, int64_t* launches);
+int uvrt_set_timing(uvrt_ctx* ctx, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,218 @@
+"""ctypes binding of the C ABI (include/uvrt.h) -- plumbing for tests and bench.py.
+
+The product is the shared library; this module only marshals numpy arrays / raw pointers
+into it.  It fails loudly when libuvrt_hip.so is missing: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuvrt_hip.so")
+
+RAY_DT = np.dtype([("dirx", "<f4"), ("diry", "<f4"), ("dirz", "<f4"),
+                   ("origx", "<f4"), ("origy", "<f4"), ("origz", "<f4"),
+                   ("dist", "<f4"), ("triID", "<u4")])
+
+MAP_SUM, MAP_MAX = 0, 1
+
+# every symbol include/uvrt.h declares: (name, restype, argtypes)
+_vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+_fp = C.POINTER(C.c_float)
+SYMBOLS = [
+    ("uvrt_last_error", C.c_char_p, []),
+    ("uvrt_version", C.c_char_p, []),
+    ("uvrt_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("uvrt_destroy", None, [_vp]),
+    ("uvrt_set_stream", C.c_int, [_vp, _vp]),
+    ("uvrt_set_scene", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    ("uvrt_resize_rays", C.c_int, [_vp, _i64]),
+    ("uvrt_reset", C.c_int, [_vp, _i32]),
+    ("uvrt_generate", C.c_int, [_vp, _fp, _f32, _i64, _i64]),
+    ("uvrt_extend", C.c_int, [_vp, _i64]),
+    ("uvrt_accumulate", C.c_int, [_vp, _f32, _i32]),
+    ("uvrt_compute_dosage", C.c_int, [_vp, _i32, _i32, _f32, _i32]),
+    ("uvrt_dosage_to_color", C.c_int, [_vp, _f32, _i32, _i32]),
+    ("uvrt_sync", C.c_int, [_vp]),
+    ("uvrt_read_dosage", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("uvrt_read_color", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("uvrt_get_seed", C.c_int, [_vp, C.POINTER(_u32)]),
+    ("uvrt_set_seed", C.c_int, [_vp, _u32]),
+    ("uvrt_seed_next", _u32, [_fp, _f32, _u32]),
+    ("uvrt_set_sort_bits", C.c_int, [_vp, _i32]),
+    ("uvrt_set_record_hits", C.c_int, [_vp, _i32]),
+    ("uvrt_set_variant", C.c_int, [_vp, _i32]),
+    ("uvrt_read_rays", C.c_int, [_vp, _vp, _i64, _i64]),
+    ("uvrt_read_counts", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("uvrt_read_photon_map", C.c_int, [_vp, _i32, _vp, _i32, _i32]),
+    ("uvrt_device_ptr", C.c_int, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i64)]),
+    ("uvrt_extend_time_ms", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    ("uvrt_set_timing", C.c_int, [_vp, _i32]),
+]
+
+_LIB = None
+
+
+class UvrtError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise UvrtError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; "
+                            "g.build()'` or `make -C small-project-uv-robot-ray-tracer_amd`). "
+                            "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def seed_next(light_pos, light_length, seed_prev):
+    return int(lib().uvrt_seed_next(_f3(light_pos), float(np.float32(light_length)), int(seed_prev)))
+
+
+class Ctx:
+    """One uvrt_ctx.  Methods mirror the ABI one to one and raise UvrtError on failure."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        self._h = None
+        self._ck(self._L.uvrt_create(int(device), C.byref(h)))
+        self._h = h
+        self.T = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise UvrtError("uvrt error %d: %s" % (rc, self._L.uvrt_last_error().decode()))
+
+    def close(self):
+        if self._h is not None:
+            self._L.uvrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._ck(self._L.uvrt_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def set_scene(self, tris, nodes, tri_idx):
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 16)
+        nodes = np.ascontiguousarray(nodes)
+        tri_idx = np.ascontiguousarray(tri_idx, dtype=np.uint32)
+        assert nodes.dtype.itemsize == 32
+        self._ck(self._L.uvrt_set_scene(self._h, _ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0],
+                                        _ptr(tri_idx)))
+        self.T = tris.shape[0]
+
+    def resize_rays(self, n):
+        self._ck(self._L.uvrt_resize_rays(self._h, int(n)))
+
+    def reset(self, reset_color=True):
+        self._ck(self._L.uvrt_reset(self._h, int(bool(reset_color))))
+
+    def generate(self, light_pos, light_length, first_gid, n):
+        self._ck(self._L.uvrt_generate(self._h, _f3(light_pos), float(np.float32(light_length)),
+                                       int(first_gid), int(n)))
+
+    def extend(self, n):
+        self._ck(self._L.uvrt_extend(self._h, int(n)))
+
+    def accumulate(self, time_step, tri_count=None):
+        self._ck(self._L.uvrt_accumulate(self._h, float(np.float32(time_step)),
+                                         self.T if tri_count is None else int(tri_count)))
+
+    def compute_dosage(self, which, photons_per_light, scaled_power, tri_count=None):
+        self._ck(self._L.uvrt_compute_dosage(self._h, int(which), int(photons_per_light),
+                                             float(np.float32(scaled_power)),
+                                             self.T if tri_count is None else int(tri_count)))
+
+    def dosage_to_color(self, min_value, threshold_view, tri_count=None):
+        self._ck(self._L.uvrt_dosage_to_color(self._h, float(np.float32(min_value)),
+                                              int(bool(threshold_view)),
+                                              self.T if tri_count is None else int(tri_count)))
+
+    def sync(self):
+        self._ck(self._L.uvrt_sync(self._h))
+
+    def read_dosage(self, first=0, count=None):
+        count = self.T - first if count is None else count
+        out = np.empty(count, dtype=np.float32)
+        self._ck(self._L.uvrt_read_dosage(self._h, _ptr(out), first, count))
+        return out
+
+    def read_color(self, first=0, count=None):
+        count = self.T - first if count is None else count
+        out = np.empty((count, 9), dtype=np.float32)
+        self._ck(self._L.uvrt_read_color(self._h, _ptr(out), first, count))
+        return out
+
+    def read_counts(self, first=0, count=None):
+        count = self.T - first if count is None else count
+        out = np.empty(count, dtype=np.int32)
+        self._ck(self._L.uvrt_read_counts(self._h, _ptr(out), first, count))
+        return out
+
+    def read_photon_map(self, which, first=0, count=None):
+        count = self.T - first if count is None else count
+        out = np.empty(count, dtype=np.float64)
+        self._ck(self._L.uvrt_read_photon_map(self._h, int(which), _ptr(out), first, count))
+        return out
+
+    def read_rays(self, first, count):
+        out = np.empty(count, dtype=RAY_DT)
+        self._ck(self._L.uvrt_read_rays(self._h, _ptr(out), int(first), int(count)))
+        return out
+
+    @property
+    def seed(self):
+        s = C.c_uint32()
+        self._ck(self._L.uvrt_get_seed(self._h, C.byref(s)))
+        return int(s.value)
+
+    @seed.setter
+    def seed(self, v):
+        self._ck(self._L.uvrt_set_seed(self._h, int(v)))
+
+    def set_sort_bits(self, bits):
+        self._ck(self._L.uvrt_set_sort_bits(self._h, int(bits)))
+
+    def set_record_hits(self, on):
+        self._ck(self._L.uvrt_set_record_hits(self._h, int(bool(on))))
+
+    def set_variant(self, v):
+        self._ck(self._L.uvrt_set_variant(self._h, int(v)))
+
+    def set_timing(self, on):
+        self._ck(self._L.uvrt_set_timing(self._h, int(bool(on))))
+
+    def extend_time_ms(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._L.uvrt_extend_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def device_ptr(self, which):
+        p, b = C.c_void_p(), C.c_int64()
+        self._ck(self._L.uvrt_device_ptr(self._h, int(which), C.byref(p), C.byref(b)))
+        return int(p.value), int(b.value)

@@ -1,0 +1,623 @@
+// uvrt_capi.hip -- the C ABI of include/uvrt.h over the HIP kernels.
+//
+// One context = one HIP device + one in-order stream + all device buffers of a RayTracer
+// (raytracer.h:50-53).  There is no CPU fallback: every entry point either runs on the GPU or
+// returns an error.
+#include "../../include/uvrt.h"
+#include "uvrt_device.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace uvrt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(UVRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                   \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need, bool zero)
+    {
+        if (need <= bytes && p) return UVRT_OK;
+        if (p) { HIP_TRY(hipFree(p)); p = nullptr; bytes = 0; }
+        if (need == 0) return UVRT_OK;
+        HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        if (zero) HIP_TRY(hipMemset(p, 0, need));
+        return UVRT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+}  // namespace
+
+struct uvrt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // scene
+    int32_t T = 0;
+    DevBuf pairs, ltris, leaf_count, area;
+    uint32_t root_ref = REF_DONE;
+    bool have_scene = false;
+
+    // per-triangle maps (raytracer.cpp:32-37)
+    DevBuf photon_map, max_map, counts, dosage, color;
+
+    // rays
+    int64_t capacity = 0;
+    DevBuf rays, keyrank, sorted, order, hits, hist, bin_start, export_buf;
+    int32_t hist_bins = 0;
+    int64_t last_n = -1;
+    int64_t last_first = 0;
+    bool last_sorted = false;
+    bool last_extended = false;
+    float ox = 0, oz = 0;
+
+    // generate.cl:6 program-scope SEED
+    uint32_t seed = 0;
+
+    // knobs
+    int32_t sort_bits = -1;
+    bool record_hits = false;
+    int32_t variant = 0;
+
+    // traversal error flag + extend timing
+    DevBuf error_flag;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int set_device(uvrt_ctx* c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return UVRT_OK;
+}
+
+// work-item 0's RNG walk of cl/generate.cl:13-39 on the host (strict f32/f64, same order)
+uint32_t host_wang_hash(uint32_t s)
+{
+    s = (s ^ 61u) ^ (s >> 16);
+    s *= 9u;
+    s = s ^ (s >> 4);
+    s *= 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    return s;
+}
+float host_random_float(uint32_t& s)
+{
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return (float)s * 2.3283064365387e-10f;
+}
+
+void split_bits(int bits, int& bphi, int& by, int& bo)
+{
+    bo = bits / 4;
+    bphi = (bits - bo + 1) / 2;
+    by = bits - bo - bphi;
+}
+
+int auto_sort_bits(int64_t n)
+{
+    // about one wave (64 rays) per key; no ordering for launches too small to matter
+    if (n < 8192) return 0;
+    int b = 0;
+    while ((int64_t(64) << (b + 1)) <= n && b < 18) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* uvrt_last_error(void) { return g_err.c_str(); }
+const char* uvrt_version(void) { return "uvrt-mi355x 0.1 (gfx950)"; }
+
+int uvrt_create(int device_id, uvrt_ctx** out)
+{
+    if (!out) return fail(UVRT_ERR_INVALID, "uvrt_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(UVRT_ERR_NO_DEVICE, "uvrt_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(UVRT_ERR_INVALID, "uvrt_create: device %d out of range [0,%d)", device_id, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(UVRT_ERR_NO_DEVICE, "uvrt_create: device %d is %s, this library is built for gfx950 only",
+                    device_id, prop.gcnArchName);
+    uvrt_ctx* c = new uvrt_ctx();
+    c->device = device_id;
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    int rc = c->error_flag.ensure(sizeof(uint32_t), true);
+    if (rc) { delete c; return rc; }
+    *out = c;
+    return UVRT_OK;
+}
+
+void uvrt_destroy(uvrt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->pairs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
+                      &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
+                      &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
+                      &c->error_flag})
+        b->release();
+    for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int uvrt_set_stream(uvrt_ctx* c, void* hip_stream)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    if (int rc = set_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return UVRT_OK;
+}
+
+int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes32,
+                   int32_t node_count, const uint32_t* tri_idx)
+{
+    if (!c || !tris64 || !nodes32 || !tri_idx) return fail(UVRT_ERR_INVALID, "uvrt_set_scene: null argument");
+    if (T <= 0 || T > MAX_TRIS || node_count <= 0)
+        return fail(UVRT_ERR_INVALID, "uvrt_set_scene: tri_count %d / node_count %d out of range", T, node_count);
+    if (int rc = set_device(c)) return rc;
+
+    struct HostNode { float mn[3]; int32_t leftFirst; float mx[3]; int32_t triCount; };
+    static_assert(sizeof(HostNode) == 32, "BVHNode is 32 bytes (bvh.h:11-21)");
+    const HostNode* nodes = (const HostNode*)nodes32;
+
+    for (int32_t i = 0; i < T; ++i)
+        if (tri_idx[i] >= (uint32_t)T)
+            return fail(UVRT_ERR_BVH, "uvrt_set_scene: triIdx[%d] = %u >= tri_count %d", i, tri_idx[i], T);
+
+    // Re-layout: walk the tree breadth-first from node 0; every inner node becomes one pair
+    // record (numbered in visit order, so the top of the tree is contiguous at the front).
+    auto leaf_ref = [&](const HostNode& n, std::vector<uint32_t>& leaf_count, int& err) -> uint32_t {
+        int64_t first = n.leftFirst, cnt = n.triCount;
+        if (first < 0 || first + cnt > T) { err = 1; return REF_DONE; }
+        leaf_count[first] = (uint32_t)cnt;
+        uint32_t code = cnt >= 15 ? 15u : (uint32_t)cnt;
+        return REF_LEAF_BIT | (code << REF_COUNT_SHIFT) | (uint32_t)first;
+    };
+    std::vector<uint32_t> leaf_count(T, 0u);
+    std::vector<PairRec> pairs;
+    std::vector<int32_t> queue;   // inner nodes in BFS order; index in queue == pair index
+    int err = 0;
+    uint32_t root_ref;
+    if (nodes[0].triCount > 0) {
+        root_ref = leaf_ref(nodes[0], leaf_count, err);
+    } else {
+        root_ref = 0;
+        queue.push_back(0);
+    }
+    for (size_t qi = 0; qi < queue.size() && !err; ++qi) {
+        const HostNode& n = nodes[queue[qi]];
+        const int64_t l = n.leftFirst;
+        if (l < 0 || l + 1 >= node_count) { err = 2; break; }
+        if (queue.size() > (size_t)node_count) { err = 3; break; }   // cycle
+        uint32_t ref[2];
+        for (int k = 0; k < 2; ++k) {
+            const HostNode& ch = nodes[l + k];
+            if (ch.triCount > 0) ref[k] = leaf_ref(ch, leaf_count, err);
+            else { ref[k] = (uint32_t)queue.size(); queue.push_back((int32_t)(l + k)); }
+        }
+        const HostNode& a = nodes[l];
+        const HostNode& b = nodes[l + 1];
+        PairRec pr;
+        pr.c0min_ref0 = make_float4(a.mn[0], a.mn[1], a.mn[2], 0.f);
+        pr.c0max_ref1 = make_float4(a.mx[0], a.mx[1], a.mx[2], 0.f);
+        memcpy(&pr.c0min_ref0.w, &ref[0], 4);
+        memcpy(&pr.c0max_ref1.w, &ref[1], 4);
+        pr.c1min = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.f);
+        pr.c1max = make_float4(b.mx[0], b.mx[1], b.mx[2], 0.f);
+        pairs.push_back(pr);
+    }
+    if (err) return fail(UVRT_ERR_BVH, "uvrt_set_scene: malformed BVH (code %d)", err);
+    if (pairs.size() >= (size_t)REF_LEAF_BIT) return fail(UVRT_ERR_BVH, "uvrt_set_scene: too many inner nodes");
+
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const bool resized = (T != c->T);
+    int rc;
+    if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false))) return rc;
+    if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri), false))) return rc;
+    if ((rc = c->leaf_count.ensure((size_t)T * 4, false))) return rc;
+    if ((rc = c->area.ensure((size_t)T * 4, false))) return rc;
+    if (resized || !c->photon_map.p) {
+        // raytracer.cpp:32-37 (the reference leaves them uninitialised until reset; zero here)
+        for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->dosage, &c->color}) b->release();
+        if ((rc = c->photon_map.ensure((size_t)T * 8, true))) return rc;
+        if ((rc = c->max_map.ensure((size_t)T * 8, true))) return rc;
+        if ((rc = c->counts.ensure((size_t)T * 4, true))) return rc;
+        if ((rc = c->dosage.ensure((size_t)T * 4, true))) return rc;
+        if ((rc = c->color.ensure((size_t)T * 36, true))) return rc;
+    }
+    if (!pairs.empty())
+        HIP_TRY(hipMemcpy(c->pairs.p, pairs.data(), pairs.size() * sizeof(PairRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->leaf_count.p, leaf_count.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    // staging copies of the reference-layout arrays for the device-side preparation kernel
+    DevBuf d_tris, d_idx;
+    if ((rc = d_tris.ensure((size_t)T * 64, false))) return rc;
+    if ((rc = d_idx.ensure((size_t)T * 4, false))) { d_tris.release(); return rc; }
+    hipError_t e1 = hipMemcpy(d_tris.p, tris64, (size_t)T * 64, hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(d_idx.p, tri_idx, (size_t)T * 4, hipMemcpyHostToDevice);
+    if (e1 == hipSuccess && e2 == hipSuccess) {
+        launch_prepare_scene(d_tris.as<float4>(), d_idx.as<uint32_t>(), c->ltris.as<LeafTri>(),
+                             c->area.as<float>(), T, c->stream);
+        e1 = hipGetLastError();
+        e2 = hipStreamSynchronize(c->stream);
+    }
+    d_tris.release();
+    d_idx.release();
+    if (e1 != hipSuccess) return fail(UVRT_ERR_HIP, "uvrt_set_scene: %s", hipGetErrorString(e1));
+    if (e2 != hipSuccess) return fail(UVRT_ERR_HIP, "uvrt_set_scene: %s", hipGetErrorString(e2));
+    c->T = T;
+    c->root_ref = root_ref;
+    c->have_scene = true;
+    return UVRT_OK;
+}
+
+int uvrt_resize_rays(uvrt_ctx* c, int64_t photon_count)
+{
+    if (!c || photon_count < 0) return fail(UVRT_ERR_INVALID, "uvrt_resize_rays: bad argument");
+    if (int rc = set_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc;
+    const size_t n = (size_t)photon_count;
+    if ((rc = c->rays.ensure(n * 16, false))) return rc;
+    if ((rc = c->keyrank.ensure(n * 8, false))) return rc;
+    if ((rc = c->sorted.ensure(n * 16, false))) return rc;
+    if ((rc = c->order.ensure(n * 4, false))) return rc;
+    if (c->record_hits && (rc = c->hits.ensure(n * 8, false))) return rc;
+    c->capacity = photon_count;
+    c->last_n = -1;
+    return UVRT_OK;
+}
+
+int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
+{
+    if (!c || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_reset: no scene");
+    if (int rc = set_device(c)) return rc;
+    launch_reset(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
+                 c->color.as<float>(), reset_color, c->T, c->stream);
+    HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+
+uint32_t uvrt_seed_next(const float lp[3], float light_length, uint32_t seed_prev)
+{
+    // work-item 0 of cl/generate.cl:13-39; the ray itself is not needed, only the RNG state
+    float acc = (float)(0 * 17 + 1);
+    acc = acc + lp[0] * 13.0f;
+    acc = acc + lp[1] * 7.0f;
+    acc = acc + lp[2] * 11.0f;
+    acc = acc + (float)(seed_prev >> 15);
+    uint32_t seed = host_wang_hash((uint32_t)(int64_t)acc);
+    (void)light_length;
+    (void)host_random_float(seed);   // origin.y
+    (void)host_random_float(seed);   // diry
+    double x = (double)(host_random_float(seed) * 2.0f - 1.0f);
+    double y = (double)(host_random_float(seed) * 2.0f - 1.0f);
+    while (x * x + y * y > 1.0) {
+        x = (double)(host_random_float(seed) * 2.0f - 1.0f);
+        y = (double)(host_random_float(seed) * 2.0f - 1.0f);
+    }
+    return seed;
+}
+
+int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t first_gid, int64_t n)
+{
+    if (!c || !lp) return fail(UVRT_ERR_INVALID, "uvrt_generate: null argument");
+    if (n < 0 || first_gid < 0 || n > c->capacity)
+        return fail(UVRT_ERR_INVALID, "uvrt_generate: n = %lld exceeds the ray capacity %lld (uvrt_resize_rays)",
+                    (long long)n, (long long)c->capacity);
+    if (first_gid + n > (int64_t)INT32_MAX)
+        return fail(UVRT_ERR_INVALID, "uvrt_generate: global id beyond int range (generate.cl:11)");
+    if (int rc = set_device(c)) return rc;
+
+    const uint32_t seed_prev = c->seed;
+    const uint32_t seed_next = uvrt_seed_next(lp, light_length, seed_prev);
+
+    int bits = c->sort_bits < 0 ? auto_sort_bits(n) : c->sort_bits;
+    if (bits > 20) bits = 20;
+    GenParams p;
+    memset(&p, 0, sizeof p);
+    p.rays = c->rays.as<float4>();
+    p.lx = lp[0]; p.ly = lp[1]; p.lz = lp[2];
+    p.light_length = light_length;
+    p.first_gid = first_gid;
+    p.n = n;
+    p.seed_prev = seed_prev;
+    p.seed_next = seed_next;
+    if (bits > 0 && n > 0) {
+        const int32_t nbins = 1 << bits;
+        if (c->hist_bins < nbins) {
+            int rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->hist.release();
+            c->bin_start.release();
+            if ((rc = c->hist.ensure((size_t)nbins * 4, true))) return rc;
+            if ((rc = c->bin_start.ensure((size_t)nbins * 4, true))) return rc;
+            c->hist_bins = nbins;
+        }
+        p.keyrank = c->keyrank.as<uint2>();
+        p.hist = c->hist.as<uint32_t>();
+        split_bits(bits, p.bits_phi, p.bits_y, p.bits_o);
+    }
+    launch_generate(p, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (p.keyrank) {
+        launch_scan_bins(c->hist.as<uint32_t>(), c->bin_start.as<uint32_t>(), 1 << bits, c->stream);
+        launch_scatter(c->rays.as<float4>(), c->keyrank.as<uint2>(), c->bin_start.as<uint32_t>(),
+                       c->sorted.as<float4>(), c->order.as<uint32_t>(), n, c->stream);
+        HIP_TRY(hipGetLastError());
+    }
+    c->seed = seed_next;
+    c->last_n = n;
+    c->last_first = first_gid;
+    c->last_sorted = p.keyrank != nullptr;
+    c->last_extended = false;
+    c->ox = lp[0];
+    c->oz = lp[2];
+    return UVRT_OK;
+}
+
+int uvrt_extend(uvrt_ctx* c, int64_t n)
+{
+    if (!c || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_extend: no scene");
+    if (c->last_n < 0 || n != c->last_n)
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: n = %lld does not match the last generate (%lld)",
+                    (long long)n, (long long)c->last_n);
+    if (int rc = set_device(c)) return rc;
+    if (c->record_hits) {
+        if (int rc = c->hits.ensure((size_t)c->capacity * 8, false)) return rc;
+    }
+    ExtendParams p;
+    memset(&p, 0, sizeof p);
+    p.scene.pairs = c->pairs.as<PairRec>();
+    p.scene.ltris = c->ltris.as<LeafTri>();
+    p.scene.leaf_count = c->leaf_count.as<uint32_t>();
+    p.scene.root_ref = c->root_ref;
+    p.scene.tri_count = c->T;
+    p.rays = c->last_sorted ? c->sorted.as<float4>() : c->rays.as<float4>();
+    p.order = c->last_sorted ? c->order.as<uint32_t>() : nullptr;
+    p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
+    p.counts = c->counts.as<int32_t>();
+    p.error_flag = c->error_flag.as<uint32_t>();
+    p.ox = c->ox;
+    p.oz = c->oz;
+    p.n = n;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            c->ev_pool.emplace_back(a, b);
+        }
+        e0 = c->ev_pool[c->ev_used].first;
+        e1 = c->ev_pool[c->ev_used].second;
+        ++c->ev_used;
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    launch_extend(p, c->variant, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
+    c->last_extended = c->record_hits;
+    return UVRT_OK;
+}
+
+int uvrt_accumulate(uvrt_ctx* c, float time_step, int32_t tri_count)
+{
+    if (!c || !c->have_scene || tri_count < 0 || tri_count > c->T)
+        return fail(UVRT_ERR_INVALID, "uvrt_accumulate: bad tri_count");
+    if (int rc = set_device(c)) return rc;
+    launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
+                      time_step, tri_count, c->stream);
+    HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+
+int uvrt_compute_dosage(uvrt_ctx* c, int32_t which, int32_t photons_per_light, float scaled_power,
+                        int32_t tri_count)
+{
+    if (!c || !c->have_scene || tri_count < 0 || tri_count > c->T)
+        return fail(UVRT_ERR_INVALID, "uvrt_compute_dosage: bad tri_count");
+    if (which != UVRT_MAP_SUM && which != UVRT_MAP_MAX)
+        return fail(UVRT_ERR_INVALID, "uvrt_compute_dosage: which_map must be 0 or 1");
+    if (int rc = set_device(c)) return rc;
+    const double* map = which == UVRT_MAP_SUM ? c->photon_map.as<double>() : c->max_map.as<double>();
+    launch_compute_dosage(map, c->dosage.as<float>(), c->area.as<float>(), photons_per_light,
+                          scaled_power, tri_count, c->stream);
+    HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+
+int uvrt_dosage_to_color(uvrt_ctx* c, float min_value, int32_t threshold_view, int32_t tri_count)
+{
+    if (!c || !c->have_scene || tri_count < 0 || tri_count > c->T)
+        return fail(UVRT_ERR_INVALID, "uvrt_dosage_to_color: bad tri_count");
+    if (int rc = set_device(c)) return rc;
+    launch_dosage_to_color(c->dosage.as<float>(), c->color.as<float>(), min_value, threshold_view,
+                           tri_count, c->stream);
+    HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+
+int uvrt_sync(uvrt_ctx* c)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    if (int rc = set_device(c)) return rc;
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, c->error_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flag) {
+        HIP_TRY(hipMemsetAsync(c->error_flag.p, 0, 4, c->stream));
+        return fail(UVRT_ERR_STACK, "extend: BVH traversal needed more than 32 stack entries (extend.cl:43)");
+    }
+    return UVRT_OK;
+}
+
+static int read_back(uvrt_ctx* c, const DevBuf& b, size_t elem, void* out, int64_t first, int64_t count,
+                     int64_t limit, const char* what)
+{
+    if (!c || !out || first < 0 || count < 0 || first + count > limit)
+        return fail(UVRT_ERR_INVALID, "%s: range [%lld,+%lld) outside [0,%lld)", what, (long long)first,
+                    (long long)count, (long long)limit);
+    if (int rc = set_device(c)) return rc;
+    if (count == 0) return UVRT_OK;
+    HIP_TRY(hipMemcpyAsync(out, (const char*)b.p + (size_t)first * elem, (size_t)count * elem,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return UVRT_OK;
+}
+
+int uvrt_read_dosage(uvrt_ctx* c, float* out, int32_t first, int32_t count)
+{
+    return read_back(c, c ? c->dosage : DevBuf(), 4, out, first, count, c ? c->T : 0, "uvrt_read_dosage");
+}
+int uvrt_read_color(uvrt_ctx* c, float* out9, int32_t first, int32_t count)
+{
+    return read_back(c, c ? c->color : DevBuf(), 36, out9, first, count, c ? c->T : 0, "uvrt_read_color");
+}
+int uvrt_read_counts(uvrt_ctx* c, int32_t* out, int32_t first, int32_t count)
+{
+    return read_back(c, c ? c->counts : DevBuf(), 4, out, first, count, c ? c->T : 0, "uvrt_read_counts");
+}
+int uvrt_read_photon_map(uvrt_ctx* c, int32_t which, double* out, int32_t first, int32_t count)
+{
+    if (which != UVRT_MAP_SUM && which != UVRT_MAP_MAX)
+        return fail(UVRT_ERR_INVALID, "uvrt_read_photon_map: which_map must be 0 or 1");
+    return read_back(c, c ? (which == UVRT_MAP_SUM ? c->photon_map : c->max_map) : DevBuf(), 8, out, first,
+                     count, c ? c->T : 0, "uvrt_read_photon_map");
+}
+
+int uvrt_get_seed(uvrt_ctx* c, uint32_t* seed)
+{
+    if (!c || !seed) return fail(UVRT_ERR_INVALID, "null argument");
+    *seed = c->seed;
+    return UVRT_OK;
+}
+int uvrt_set_seed(uvrt_ctx* c, uint32_t seed)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    c->seed = seed;
+    return UVRT_OK;
+}
+
+int uvrt_set_sort_bits(uvrt_ctx* c, int32_t bits)
+{
+    if (!c || bits < -1 || bits > 20) return fail(UVRT_ERR_INVALID, "uvrt_set_sort_bits: bits must be in [-1,20]");
+    c->sort_bits = bits;
+    return UVRT_OK;
+}
+int uvrt_set_record_hits(uvrt_ctx* c, int32_t on)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    c->record_hits = on != 0;
+    return UVRT_OK;
+}
+int uvrt_set_variant(uvrt_ctx* c, int32_t variant)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    c->variant = variant;
+    return UVRT_OK;
+}
+int uvrt_set_timing(uvrt_ctx* c, int32_t on)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    c->timing = on != 0;
+    return UVRT_OK;
+}
+
+int uvrt_read_rays(uvrt_ctx* c, void* rays32, int64_t first, int64_t count)
+{
+    if (!c || !rays32 || c->last_n < 0 || first < 0 || count < 0 || first + count > c->last_n)
+        return fail(UVRT_ERR_INVALID, "uvrt_read_rays: range outside the last generate");
+    if (int rc = set_device(c)) return rc;
+    if (count == 0) return UVRT_OK;
+    if (int rc = c->export_buf.ensure((size_t)count * 32, false)) return rc;
+    const uint2* hits = (c->last_extended && c->hits.p) ? c->hits.as<uint2>() : nullptr;
+    launch_export_rays(c->rays.as<float4>(), hits, c->export_buf.p, c->ox, c->oz, first, count, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rays32, c->export_buf.p, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return UVRT_OK;
+}
+
+int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
+{
+    if (!c || !ptr || !bytes || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: bad argument");
+    const DevBuf* b = nullptr;
+    size_t elem = 0;
+    switch (which) {
+        case 0: b = &c->photon_map; elem = 8; break;
+        case 1: b = &c->max_map; elem = 8; break;
+        case 2: b = &c->counts; elem = 4; break;
+        case 3: b = &c->dosage; elem = 4; break;
+        case 4: b = &c->color; elem = 36; break;
+        default: return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: which must be 0..4");
+    }
+    *ptr = b->p;
+    *bytes = (int64_t)((size_t)c->T * elem);
+    return UVRT_OK;
+}
+
+int uvrt_extend_time_ms(uvrt_ctx* c, double* ms, int64_t* launches)
+{
+    if (!c || !ms || !launches) return fail(UVRT_ERR_INVALID, "null argument");
+    if (int rc = set_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double total = 0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[i].first, c->ev_pool[i].second));
+        total += t;
+    }
+    *ms = total;
+    *launches = (int64_t)c->ev_used;
+    c->ev_used = 0;
+    return UVRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// uvrt_device.h -- device-side record layouts and kernel launch wrappers (gfx950 only).
+//
+// HBM layout of one context (see DESIGN.md "Data layout"):
+//   pairs    : one 64-byte record per INNER node = the AABBs of its two children plus a 32-bit
+//              reference to each child.  The reference's traversal always touches the two
+//              children of a node together (extend.cl:56-59), so one aligned 64-byte record
+//              (4 x dwordx4) replaces two 32-byte BVHNode gathers.
+//   ltris    : one 48-byte record per triIdx slot (leaf order): v0, e1 = v1-v0, e2 = v2-v0 and
+//              the original triangle id.  Replaces the triIdx[] -> Triangle[] double
+//              indirection of extend.cl:50-53.
+//   rays     : 16 bytes per photon {dir.xyz, orig.y}; orig.x / orig.z are the lamp's and are
+//              launch-uniform (generate.cl:16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uvrt {
+
+constexpr uint32_t REF_LEAF_BIT = 0x80000000u;   // bit 31: leaf reference
+constexpr uint32_t REF_DONE = 0xFFFFFFFFu;       // traversal finished
+constexpr uint32_t REF_FIRST_MASK = 0x07FFFFFFu; // leaf: first slot in ltris (27 bits)
+constexpr int REF_COUNT_SHIFT = 27;              // leaf: 4-bit count code, 15 = see leaf_count[]
+constexpr int MAX_TRIS = 1 << 27;
+
+struct alignas(16) PairRec {   // 64 B
+    float4 c0min_ref0;         // child0 min.xyz, bits of ref0
+    float4 c0max_ref1;         // child0 max.xyz, bits of ref1
+    float4 c1min;              // child1 min.xyz, 0
+    float4 c1max;              // child1 max.xyz, 0
+};
+
+struct alignas(16) LeafTri {   // 48 B
+    float4 v0_id;              // v0.xyz, bits of the original triangle id
+    float4 e1;                 // v1 - v0 (one f32 subtraction per component, extend.cl:13)
+    float4 e2;                 // v2 - v0
+};
+
+struct SceneDev {
+    const PairRec* pairs;
+    const LeafTri* ltris;
+    const uint32_t* leaf_count;  // per ltris slot: triangle count of the leaf starting there
+    uint32_t root_ref;
+    int32_t tri_count;
+};
+
+struct GenParams {
+    float4* rays;          // [n] gid order: dir.xyz, orig.y
+    uint2* keyrank;        // [n] (key, rank within key) or nullptr when not sorting
+    uint32_t* hist;        // [1 << sort_bits]
+    float lx, ly, lz;      // lamp position (generate.cl arg 1)
+    float light_length;    // generate.cl arg 2
+    int64_t first_gid;
+    int64_t n;
+    uint32_t seed_prev;    // SEED_{k-1}: read by work-item 0
+    uint32_t seed_next;    // SEED_k: read by everybody else
+    int32_t bits_phi, bits_y, bits_o;
+};
+
+struct ExtendParams {
+    SceneDev scene;
+    const float4* rays;      // [n] in trace order
+    const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)
+    uint2* hits;             // [n] by local ray index: (dist bits, triID), or nullptr
+    int32_t* counts;         // tempPhotonMap
+    uint32_t* error_flag;    // set to 1 on traversal stack overflow
+    float ox, oz;            // launch-uniform origin components
+    int64_t n;
+};
+
+// launch wrappers (uvrt_kernels.hip)
+void launch_generate(const GenParams& p, hipStream_t s);
+void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStream_t s);
+void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bin_start,
+                    float4* sorted, uint32_t* order, int64_t n, hipStream_t s);
+void launch_extend(const ExtendParams& p, int variant, hipStream_t s);
+void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, float time_step,
+                       int32_t T, hipStream_t s);
+void launch_reset(double* photon_map, double* max_map, int32_t* counts, float* color,
+                  int32_t reset_color, int32_t T, hipStream_t s);
+void launch_compute_dosage(const double* map, float* dosage, const float* area,
+                           int32_t photons_per_light, float scaled_power, int32_t T,
+                           hipStream_t s);
+void launch_dosage_to_color(const float* dosage, float* color, float min_value,
+                            int32_t threshold_view, int32_t T, hipStream_t s);
+void launch_prepare_scene(const float4* tris64, const uint32_t* tri_idx, LeafTri* ltris,
+                          float* area, int32_t T, hipStream_t s);
+void launch_export_rays(const float4* rays, const uint2* hits, void* out32, float ox, float oz,
+                        int64_t first, int64_t count, hipStream_t s);
+
+}  // namespace uvrt

@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GLB = os.path.join(GOLDEN, "testroomopt.glb")
+ROUTE = os.path.join(GOLDEN, "lange_route.xml")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import __graft_entry__ as g
+    return g.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="session")
+def oscene(orc):
+    """The test scene through the ORACLE's loader / floor / BVH restatement."""
+    return orc.Scene(GLB)
+
+
+@pytest.fixture(scope="session")
+def oroute(orc):
+    return orc.load_route(ROUTE)

@@ -1,0 +1,182 @@
+"""GPU parity tests proper: every HIP kernel, called through the C ABI, against the CPU oracle
+on the same seeded inputs.  Bar: bit-exact (rays, hit distances, triangle ids, integer photon
+counts, f64 maps, f32 dose and colours)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg, oscene):
+    c = pkg.capi.Ctx(0)
+    c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+    yield c
+    c.close()
+
+
+def lamp_pos(orc, oscene, oroute, k):
+    comp = orc.Computation(oscene, oroute["lamps"], 1 << 16, oroute["lightHeight"],
+                           oroute["lightLength"], oroute["lightIntensity"])
+    return tuple(float(x) for x in comp.lamp_world_pos(oroute["lamps"][k]))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,first", [(1, 0), (63, 0), (4096, 0), (100000, 0), (5000, 777), (1, 12345)])
+def test_generate_bit_exact(ctx, orc, oscene, oroute, n, first):
+    lp = lamp_pos(orc, oscene, oroute, 0)
+    ctx.resize_rays(max(n, 1))
+    for seed0 in (0, 0x79044923):
+        ctx.seed = seed0
+        ctx.generate(lp, oroute["lightLength"], first, n)
+        got = ctx.read_rays(0, n)
+        ref, seed1 = orc.generate(first, n, lp, oroute["lightLength"], seed0)
+        assert ctx.seed == seed1
+        for f in ("dirx", "diry", "dirz", "origx", "origy", "origz", "dist"):
+            assert np.array_equal(bits(got[f]), bits(ref[f])), f
+        assert np.array_equal(got["triID"], ref["triID"])
+
+
+def test_seed_chain_matches_survey(pkg):
+    # SURVEY.md 8c "Pinned SEED semantics"
+    s1 = pkg.capi.seed_next((-0.25500134, -0.99548361, -3.3149862), 1.0, 0)
+    assert s1 == 0x79044923
+    s2 = pkg.capi.seed_next((-1.1050029, -0.99548361, -3.2301083), 1.0, s1)
+    assert s2 == 0xce0db3eb
+
+
+@pytest.mark.parametrize("sort_bits", [0, 6, 12, -1])
+def test_extend_hits_and_counts_bit_exact(ctx, orc, oscene, oroute, sort_bits):
+    n = 200000
+    lp = lamp_pos(orc, oscene, oroute, 3)
+    ctx.set_sort_bits(sort_bits)
+    ctx.set_record_hits(True)
+    ctx.resize_rays(n)
+    ctx.reset(False)
+    ctx.seed = 0
+    ctx.generate(lp, oroute["lightLength"], 0, n)
+    ctx.extend(n)
+    ctx.sync()
+    got = ctx.read_rays(0, n)
+    counts = ctx.read_counts()
+    rays, _ = orc.generate(0, n, lp, oroute["lightLength"], 0)
+    temp = np.zeros(oscene.T, dtype=np.int32)
+    st = orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+    assert st["hits"] > 0.5 * n
+    assert np.array_equal(bits(got["dist"]), bits(rays["dist"]))
+    assert np.array_equal(got["triID"], rays["triID"])
+    assert np.array_equal(counts, temp)
+    ctx.set_sort_bits(-1)
+    ctx.set_record_hits(False)
+
+
+def test_full_iteration_two_lamps_matches_survey_golden(ctx, orc, oscene, oroute):
+    """generate -> extend -> accumulate per lamp, then computeDosage: SURVEY.md 8c golden run
+    (N = 65 536, lamps 0 and 1) and the oracle, bit for bit."""
+    import json, os
+    from conftest import GOLDEN
+    gold = json.load(open(os.path.join(GOLDEN, "survey_8c.json")))["runs"][0]
+    lamps = oroute["lamps"][:2]
+    comp = orc.Computation(oscene, lamps, gold["photonCount"], oroute["lightHeight"],
+                           oroute["lightLength"], oroute["lightIntensity"])
+    comp.reset()
+    comp.iteration()
+    ref_dose = comp.dose()
+    ppl = comp.photonsPerLight
+    ctx.resize_rays(ppl)
+    ctx.reset(True)
+    ctx.seed = 0
+    size = 0
+    for lamp in lamps:
+        lp = comp.lamp_world_pos(lamp)
+        ctx.generate(lp, oroute["lightLength"], 0, ppl)
+        ctx.extend(ppl)
+        ctx.accumulate(lamp[2])
+        size += ppl
+    scaled = np.float32(np.float32(oroute["lightIntensity"]) * np.float32(0.1))
+    ctx.compute_dosage(pkg_map_sum(), size // len(lamps), scaled)
+    ctx.sync()
+    dose = ctx.read_dosage()
+    assert np.array_equal(ctx.read_photon_map(0), comp.photonMap)
+    assert np.array_equal(ctx.read_photon_map(1), comp.maxPhotonMap)
+    assert np.array_equal(bits(dose), bits(ref_dose))
+    assert np.allclose(dose[:8], gold["dose_0_7"], rtol=1e-7)
+    assert abs(float(dose.astype(np.float64).sum()) - gold["dose_sum"]) < 0.01
+    assert int((dose != 0).sum()) == gold["dose_nonzero"]
+    assert ctx.seed == 0xce0db3eb
+    # max-power view + colours
+    ctx.compute_dosage(1, ppl, np.float32(np.float32(oroute["lightIntensity"]) * np.float32(100)))
+    ctx.dosage_to_color(oroute["minPower"], False)
+    ctx.sync()
+    mp = ctx.read_dosage()
+    assert np.array_equal(bits(mp), bits(comp.max_power()))
+    col = ctx.read_color()
+    assert np.array_equal(bits(col), bits(orc.dosage_to_color(mp, oroute["minPower"], False)))
+    ctx.dosage_to_color(oroute["minPower"], True)
+    ctx.sync()
+    assert np.array_equal(bits(ctx.read_color()), bits(orc.dosage_to_color(mp, oroute["minPower"], True)))
+
+
+def pkg_map_sum():
+    return 0
+
+
+def test_reset_clears_maps(ctx):
+    ctx.reset(True)
+    ctx.sync()
+    assert not ctx.read_photon_map(0).any()
+    assert not ctx.read_photon_map(1).any()
+    assert not ctx.read_counts().any()
+    assert not ctx.read_color().any()
+
+
+def test_root_leaf_scene(pkg, orc):
+    """CalibratePower's scene: two triangles under a single leaf root (raytracer.cpp:158-187)."""
+    tris = np.zeros((2, 16), dtype=np.float32)
+    h, d, w = np.float32(-0.5), np.float32(1.0), np.float32(0.1)
+    tris[0, 0:3] = (w, h + w, d); tris[0, 4:7] = (-w, h + w, d); tris[0, 8:11] = (w, h - w, d)
+    tris[1, 0:3] = (-w, h - w, d); tris[1, 4:7] = (-w, h + w, d); tris[1, 8:11] = (w, h - w, d)
+    nodes = np.zeros(1, dtype=orc.NODE_DT)
+    nodes[0]["leftFirst"] = 0
+    nodes[0]["triCount"] = 2
+    idx = np.array([0, 1], dtype=np.uint32)
+    c = pkg.capi.Ctx(0)
+    try:
+        c.set_scene(tris, nodes, idx)
+        n = 300000
+        c.resize_rays(n)
+        c.set_record_hits(True)
+        c.reset(False)
+        lp = (0.0, -1.0, 0.0)
+        c.generate(lp, 1.0, 0, n)
+        c.extend(n)
+        c.sync()
+        got = c.read_rays(0, n)
+        counts = c.read_counts()
+        rays, _ = orc.generate(0, n, lp, 1.0, 0)
+        temp = np.zeros(2, dtype=np.int32)
+        orc.extend(temp, tris, rays, nodes, idx)
+        assert temp.sum() > 0
+        assert np.array_equal(counts, temp)
+        assert np.array_equal(bits(got["dist"]), bits(rays["dist"]))
+        assert np.array_equal(got["triID"], rays["triID"])
+    finally:
+        c.close()
+
+
+def test_no_scene_is_an_error(pkg):
+    c = pkg.capi.Ctx(0)
+    try:
+        with pytest.raises(pkg.capi.UvrtError):
+            c.reset(True)
+        c.resize_rays(16)
+        c.generate((0, 0, 0), 1.0, 0, 16)
+        with pytest.raises(pkg.capi.UvrtError):
+            c.extend(16)
+        with pytest.raises(pkg.capi.UvrtError):
+            c.generate((0, 0, 0), 1.0, 0, 17)   # beyond capacity
+    finally:
+        c.close()

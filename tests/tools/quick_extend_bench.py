@@ -1,0 +1,44 @@
+"""Developer probe (not the bench): time extend for a few knob settings on lamp 0, checking
+counts against the oracle once.  Lives under tests/ because it uses the oracle's scene loader."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+
+pkg = g.load_package(); orc = g.load_oracle()
+glb = os.path.join(ROOT, "tests/golden/testroomopt.glb")
+route = orc.load_route(os.path.join(ROOT, "tests/golden/lange_route.xml"))
+s = orc.Scene(glb)
+comp = orc.Computation(s, route["lamps"], 1 << 16, route["lightHeight"], route["lightLength"], route["lightIntensity"])
+lp = comp.lamp_world_pos(route["lamps"][0])
+n = int(os.environ.get("N", 2073600))
+variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+sorts = [int(v) for v in os.environ.get("SORTS", "0,-1,12,15,18").split(",")]
+c = pkg.capi.Ctx(0)
+c.set_scene(s.tris, s.nodes, s.triIdx)
+c.resize_rays(n)
+ref = None
+if os.environ.get("CHECK", "1") == "1":
+    rays, _ = orc.generate(0, n, lp, route["lightLength"], 0)
+    ref = np.zeros(s.T, dtype=np.int32)
+    st = orc.extend(ref, s.tris, rays, s.nodes, s.triIdx)
+    print("oracle stats", st, "B/ray %.1f" % orc.algorithmic_bytes_per_ray(st), flush=True)
+for v in variants:
+    for sb in sorts:
+        c.set_variant(v); c.set_sort_bits(sb); c.set_timing(True)
+        c.reset(False); c.seed = 0
+        c.generate(lp, route["lightLength"], 0, n); c.extend(n); c.sync()
+        ok = "-"
+        if ref is not None:
+            ok = "OK" if np.array_equal(c.read_counts(), ref) else "MISMATCH"
+        c.extend_time_ms()
+        reps = 5
+        c.sync(); t0 = time.time()
+        for _ in range(reps):
+            c.seed = 0
+            c.generate(lp, route["lightLength"], 0, n); c.extend(n); c.accumulate(60.0)
+        c.sync(); wall = (time.time() - t0) / reps
+        ms, k = c.extend_time_ms()
+        print("variant %d sort_bits %3d: counts %s  extend %.3f ms  (%.1f Mray/s)  wave wall %.3f ms (%.1f Mray/s)"
+              % (v, sb, ok, ms / k, n / (ms / k) / 1e3, wall * 1e3, n / wall / 1e6), flush=True)
