@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on one node: Mray/s of the UV-dose hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], mapped as SURVEY.md section 0 prescribes): rooms/C046_1.glb
+is absent from the reference checkout, so its stand-in is the reference's only shipped scene,
+testroomopt.glb (44 866 triangles vs 46 252); "1920x1080" = 2 073 600 photons per lamp launch;
+"8-bounce" = 8 waves of the reference's one-segment photon pass (the reference has no bounces);
+lamp 0 of positions/lange_route.xml; SEED_0 = 0.
+
+One STEP = one whole computation by the reference's own host loop (RayTracer, myapp.cpp:156-175):
+ResetDosageMap, then per wave generate -> extend -> accumulate and Shade (computeDosage +
+dosageToColor), then -- with N > 1 -- the one reduction of the per-triangle maps over RCCL,
+a final Shade and a sync.  Inputs (scene, BVH) are resident in HBM before the timed region.
+
+Scaling is WEAK: every GPU traces 8 waves; with N GPUs the computation has 8*N waves (launch k
+runs on rank k % N, raytracer.h shardRank/shardWorld), so `value` = 8*N*2 073 600 rays / time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PHOTONS = 1920 * 1080
+WAVES = 8
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+
+
+def census_path():
+    return os.path.join(ROOT, "tests", "golden", "census_lamp0_%d.json" % PHOTONS)
+
+
+def cpu_baseline(glb, route_xml, waves, photons):
+    """The oracle (CPU restatement of the reference kernels, OpenMP on all host cores) timed on
+    the same workload: `waves` launches of `photons` photons from lamp 0.  Also returns the
+    traversal census that prices the algorithmic bytes per ray."""
+    import __graft_entry__ as g
+    orc = g.load_oracle()
+    import numpy as np
+    s = orc.Scene(glb)
+    r = orc.load_route(route_xml)
+    cores = os.cpu_count() or 1
+    c = orc.Computation(s, r["lamps"][:1], photons, r["lightHeight"], r["lightLength"], r["lightIntensity"],
+                        nthreads=cores)
+    c.reset()
+    t_gen = t_ext = 0.0
+    lamp = r["lamps"][0]
+    lp = c.lamp_world_pos(lamp)
+    t0 = time.time()
+    for _ in range(waves):
+        a = time.time()
+        rays, c.SEED = orc.generate(0, photons, lp, c.lightLength, c.SEED)
+        b = time.time()
+        st = orc.extend(c.temp, s.tris, rays, s.nodes, s.triIdx, cores)
+        d = time.time()
+        orc.accumulate(c.photonMap, c.maxPhotonMap, c.temp, lamp[2])
+        c.photonMapSize += photons
+        c.stats.append(st)
+        t_gen += b - a
+        t_ext += d - b
+    dose = c.dose()
+    total = time.time() - t0
+    tot = {k: sum(x[k] for x in c.stats) for k in ("rays", "aabb_tests", "tri_tests", "hits", "node_visits")}
+    return {
+        "value": waves * photons / total / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "sample": "%d waves x %d photons, lamp 0 (the full step); generate is serial (defines the SEED "
+                  "semantics), extend uses %d OpenMP threads; extend-only %.2f Mray/s"
+                  % (waves, photons, cores, waves * photons / t_ext / 1e6),
+    }, tot, dose
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--photons", type=int, default=PHOTONS)
+    ap.add_argument("--waves", type=int, default=WAVES, help="waves (iterations) per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sort-bits", type=int, default=None)
+    ap.add_argument("--variant", type=int, default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import __graft_entry__ as g
+    g.load_package()
+    from uvrt_amd import host, sharding
+
+    glb = os.path.join(ROOT, "tests", "golden", "testroomopt.glb")
+    route_xml = os.path.join(ROOT, "tests", "golden", "lange_route.xml")
+
+    # ---- product path: native loader + BVH + RayTracer on the HIP kernels -----------------
+    rt = host.RayTracer(glb, route_xml, device=local_rank)
+    rt.set_lamps(rt.lamps()[:1])              # lamp 0
+    rt.photonCount = args.photons
+    rt.maxIterations = args.waves * world
+    rt.set_shard(rank, world)
+    stream = torch.cuda.current_stream(device)
+    rt.ctx.set_stream(stream.cuda_stream)      # kernels and the collective share torch's stream
+    if args.sort_bits is not None:
+        rt.ctx.set_sort_bits(args.sort_bits)
+    if args.variant is not None:
+        rt.ctx.set_variant(args.variant)
+    reducer = sharding.MapReducer(rt.ctx, device) if world > 1 else None
+
+    def step():
+        rt.ResetDosageMap()
+        rt.set_shard(rank, world)             # restart the global launch index
+        for _ in range(rt.maxIterations):     # myapp.cpp:156-163
+            rt.ComputeDosageMap()
+            rt.Shade()
+            rt.currIterations = rt.currIterations + 1
+        if reducer is not None:
+            reducer()
+            rt.Shade()
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    rt.ctx.set_timing(True)
+    rt.ctx.extend_time_ms()                    # drop anything recorded so far
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ext_ms, ext_launches = rt.ctx.extend_time_ms()
+    rt.ctx.set_timing(False)
+    rt.Sync()                                  # surfaces a traversal-stack overflow, if any
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    rays_per_step = rt.maxIterations * rt.photonsPerLight
+    value = rays_per_step * args.steps / elapsed / 1e6
+    dose = rt.read_dosage()
+
+    if rank == 0:
+        # ---- CPU baseline + census (rank 0, N = 1 only) -----------------------------------
+        cpu = None
+        census = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, census, ref_dose = cpu_baseline(glb, route_xml, args.waves, args.photons)
+            same = np.array_equal(dose.view(np.uint32), ref_dose.view(np.uint32))
+            cpu["gpu_dose_bit_identical"] = bool(same)
+            if not same:
+                print("WARNING: GPU dose differs from the oracle", file=sys.stderr)
+        if census is None and os.path.exists(census_path()) and args.photons == PHOTONS:
+            census = json.load(open(census_path()))["per_launch_avg"]
+            n_census = 1
+        else:
+            n_census = args.waves
+        roof = None
+        if census is not None:
+            n = float(census["rays"])
+            bytes_per_ray = (32.0 + 8.0 + 32.0 * (1.0 + census["aabb_tests"] / n)
+                             + 68.0 * census["tri_tests"] / n + 4.0 * census["hits"] / n)
+            avg_ms = ext_ms / max(ext_launches, 1)
+            achieved = bytes_per_ray * rt.photonsPerLight / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "extend_pmc.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            roof = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
+                    "rays_per_launch": rt.photonsPerLight, "avg_launch_ms": round(avg_ms, 4),
+                    "extend_mray_s": round(rt.photonsPerLight / avg_ms / 1e3, 1)}
+        out = {
+            "metric": "Mray/s (extend+shade) on C046_1.glb 1920x1080x8-bounce", "value": round(value, 2),
+            "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "testroomopt.glb (stand-in for the absent rooms/C046_1.glb), %d photons/launch "
+                                   "x %d waves per GPU, lamp 0 of lange_route.xml, SEED_0=0; step = reset + waves x "
+                                   "(generate, extend, accumulate, shade)%s + sync"
+                                   % (rt.photonsPerLight, args.waves, " + RCCL SUM/MAX of the per-triangle maps"
+                                      if world > 1 else ""),
+                       "triangles": rt.mesh.triangleCount, "rays_per_step": rays_per_step,
+                       "parallelism": "launch-sharded x%d" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    rt.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,8 +107,8 @@ int uvrt_set_seed(uvrt_ctx* ctx, uint32_t seed);
 uint32_t uvrt_seed_next(const float light_pos[3], float light_length, uint32_t seed_prev);
 
 /* ---- tuning knobs (results never depend on them) ---- */
-/* bits of the ray-coherence key used to order rays before extend; 0 = trace in gid order,
- * -1 = choose from n (default). */
+/* bits of the ray-coherence key used to order rays before extend; 0 = trace in gid order
+ * (default), -1 = choose from n (about one wavefront of rays per key). */
 int uvrt_set_sort_bits(uvrt_ctx* ctx, int32_t bits);
 /* record (dist, triID) per ray in gid order during extend (the reference updates rays in
  * place, extend.cl:90-92); off by default, needed by uvrt_read_rays. */
@@ -127,6 +127,10 @@ int uvrt_read_photon_map(uvrt_ctx* ctx, int32_t which_map, double* out, int32_t 
  * tensors handed to an RCCL collective).  which: 0 photonMap f64[T], 1 maxPhotonMap f64[T],
  * 2 tempPhotonMap i32[T], 3 dosageMap f32[T], 4 colour f32[9T]. */
 int uvrt_device_ptr(uvrt_ctx* ctx, int32_t which, void** ptr, int64_t* bytes);
+/* copy one of those arrays to (to_ctx = 0) or from (to_ctx = 1) an external device buffer of the
+ * same size, on the context's stream (staging for collectives when zero-copy wrapping is not
+ * available). */
+int uvrt_copy_device(uvrt_ctx* ctx, int32_t which, void* ext_dev_ptr, int32_t to_ctx);
 /* time in ms the device spent in the extend kernels since the last call (HIP events on the
  * context's stream), and the number of extend launches; synchronises. */
 int uvrt_extend_time_ms(uvrt_ctx* ctx, double* ms, int64_t* launches);

@@ -49,6 +49,7 @@ SYMBOLS = [
     ("uvrt_read_counts", C.c_int, [_vp, _vp, _i32, _i32]),
     ("uvrt_read_photon_map", C.c_int, [_vp, _i32, _vp, _i32, _i32]),
     ("uvrt_device_ptr", C.c_int, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i64)]),
+    ("uvrt_copy_device", C.c_int, [_vp, _i32, _vp, _i32]),
     ("uvrt_extend_time_ms", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("uvrt_set_timing", C.c_int, [_vp, _i32]),
 ]
@@ -211,6 +212,9 @@ class Ctx:
         ms, n = C.c_double(), C.c_int64()
         self._ck(self._L.uvrt_extend_time_ms(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    def copy_device(self, which, ext_ptr, to_ctx):
+        self._ck(self._L.uvrt_copy_device(self._h, int(which), C.c_void_p(int(ext_ptr)), int(bool(to_ctx))))
 
     def device_ptr(self, which):
         p, b = C.c_void_p(), C.c_int64()

@@ -41,14 +41,17 @@ int fail(int code, const char* fmt, ...)
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
-    int ensure(size_t need, bool zero)
+    // Zeroing is enqueued on `s`, the stream every kernel of the context runs on (the
+    // context's stream is non-blocking, so a null-stream hipMemset would not be ordered
+    // against it).
+    int ensure(size_t need, bool zero, hipStream_t s)
     {
         if (need <= bytes && p) return UVRT_OK;
         if (p) { HIP_TRY(hipFree(p)); p = nullptr; bytes = 0; }
         if (need == 0) return UVRT_OK;
         HIP_TRY(hipMalloc(&p, need));
         bytes = need;
-        if (zero) HIP_TRY(hipMemset(p, 0, need));
+        if (zero) HIP_TRY(hipMemsetAsync(p, 0, need, s));
         return UVRT_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -85,7 +88,7 @@ struct uvrt_ctx {
     uint32_t seed = 0;
 
     // knobs
-    int32_t sort_bits = -1;
+    int32_t sort_bits = 0;   // ray ordering off by default: extend is VALU-bound
     bool record_hits = false;
     int32_t variant = 0;
 
@@ -165,7 +168,7 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     HIP_TRY(hipSetDevice(device_id));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    int rc = c->error_flag.ensure(sizeof(uint32_t), true);
+    int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
     if (rc) { delete c; return rc; }
     *out = c;
     return UVRT_OK;
@@ -259,28 +262,28 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     HIP_TRY(hipStreamSynchronize(c->stream));
     const bool resized = (T != c->T);
     int rc;
-    if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false))) return rc;
-    if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri), false))) return rc;
-    if ((rc = c->leaf_count.ensure((size_t)T * 4, false))) return rc;
-    if ((rc = c->area.ensure((size_t)T * 4, false))) return rc;
+    if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
+    if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri), false, c->stream))) return rc;
+    if ((rc = c->leaf_count.ensure((size_t)T * 4, false, c->stream))) return rc;
+    if ((rc = c->area.ensure((size_t)T * 4, false, c->stream))) return rc;
     if (resized || !c->photon_map.p) {
         // raytracer.cpp:32-37 (the reference leaves them uninitialised until reset; zero here)
         for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->dosage, &c->color}) b->release();
-        if ((rc = c->photon_map.ensure((size_t)T * 8, true))) return rc;
-        if ((rc = c->max_map.ensure((size_t)T * 8, true))) return rc;
-        if ((rc = c->counts.ensure((size_t)T * 4, true))) return rc;
-        if ((rc = c->dosage.ensure((size_t)T * 4, true))) return rc;
-        if ((rc = c->color.ensure((size_t)T * 36, true))) return rc;
+        if ((rc = c->photon_map.ensure((size_t)T * 8, true, c->stream))) return rc;
+        if ((rc = c->max_map.ensure((size_t)T * 8, true, c->stream))) return rc;
+        if ((rc = c->counts.ensure((size_t)T * 4, true, c->stream))) return rc;
+        if ((rc = c->dosage.ensure((size_t)T * 4, true, c->stream))) return rc;
+        if ((rc = c->color.ensure((size_t)T * 36, true, c->stream))) return rc;
     }
     if (!pairs.empty())
-        HIP_TRY(hipMemcpy(c->pairs.p, pairs.data(), pairs.size() * sizeof(PairRec), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->leaf_count.p, leaf_count.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(c->pairs.p, pairs.data(), pairs.size() * sizeof(PairRec), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->leaf_count.p, leaf_count.data(), (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
     // staging copies of the reference-layout arrays for the device-side preparation kernel
     DevBuf d_tris, d_idx;
-    if ((rc = d_tris.ensure((size_t)T * 64, false))) return rc;
-    if ((rc = d_idx.ensure((size_t)T * 4, false))) { d_tris.release(); return rc; }
-    hipError_t e1 = hipMemcpy(d_tris.p, tris64, (size_t)T * 64, hipMemcpyHostToDevice);
-    hipError_t e2 = hipMemcpy(d_idx.p, tri_idx, (size_t)T * 4, hipMemcpyHostToDevice);
+    if ((rc = d_tris.ensure((size_t)T * 64, false, c->stream))) return rc;
+    if ((rc = d_idx.ensure((size_t)T * 4, false, c->stream))) { d_tris.release(); return rc; }
+    hipError_t e1 = hipMemcpyAsync(d_tris.p, tris64, (size_t)T * 64, hipMemcpyHostToDevice, c->stream);
+    hipError_t e2 = hipMemcpyAsync(d_idx.p, tri_idx, (size_t)T * 4, hipMemcpyHostToDevice, c->stream);
     if (e1 == hipSuccess && e2 == hipSuccess) {
         launch_prepare_scene(d_tris.as<float4>(), d_idx.as<uint32_t>(), c->ltris.as<LeafTri>(),
                              c->area.as<float>(), T, c->stream);
@@ -301,14 +304,15 @@ int uvrt_resize_rays(uvrt_ctx* c, int64_t photon_count)
 {
     if (!c || photon_count < 0) return fail(UVRT_ERR_INVALID, "uvrt_resize_rays: bad argument");
     if (int rc = set_device(c)) return rc;
+    if (photon_count == c->capacity && c->rays.p && (!c->record_hits || c->hits.p)) { c->last_n = -1; return UVRT_OK; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc;
     const size_t n = (size_t)photon_count;
-    if ((rc = c->rays.ensure(n * 16, false))) return rc;
-    if ((rc = c->keyrank.ensure(n * 8, false))) return rc;
-    if ((rc = c->sorted.ensure(n * 16, false))) return rc;
-    if ((rc = c->order.ensure(n * 4, false))) return rc;
-    if (c->record_hits && (rc = c->hits.ensure(n * 8, false))) return rc;
+    if ((rc = c->rays.ensure(n * 16, false, c->stream))) return rc;
+    if ((rc = c->keyrank.ensure(n * 8, false, c->stream))) return rc;
+    if ((rc = c->sorted.ensure(n * 16, false, c->stream))) return rc;
+    if ((rc = c->order.ensure(n * 4, false, c->stream))) return rc;
+    if (c->record_hits && (rc = c->hits.ensure(n * 8, false, c->stream))) return rc;
     c->capacity = photon_count;
     c->last_n = -1;
     return UVRT_OK;
@@ -376,8 +380,8 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->hist.release();
             c->bin_start.release();
-            if ((rc = c->hist.ensure((size_t)nbins * 4, true))) return rc;
-            if ((rc = c->bin_start.ensure((size_t)nbins * 4, true))) return rc;
+            if ((rc = c->hist.ensure((size_t)nbins * 4, true, c->stream))) return rc;
+            if ((rc = c->bin_start.ensure((size_t)nbins * 4, true, c->stream))) return rc;
             c->hist_bins = nbins;
         }
         p.keyrank = c->keyrank.as<uint2>();
@@ -410,7 +414,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
                     (long long)n, (long long)c->last_n);
     if (int rc = set_device(c)) return rc;
     if (c->record_hits) {
-        if (int rc = c->hits.ensure((size_t)c->capacity * 8, false)) return rc;
+        if (int rc = c->hits.ensure((size_t)c->capacity * 8, false, c->stream)) return rc;
     }
     ExtendParams p;
     memset(&p, 0, sizeof p);
@@ -576,7 +580,7 @@ int uvrt_read_rays(uvrt_ctx* c, void* rays32, int64_t first, int64_t count)
         return fail(UVRT_ERR_INVALID, "uvrt_read_rays: range outside the last generate");
     if (int rc = set_device(c)) return rc;
     if (count == 0) return UVRT_OK;
-    if (int rc = c->export_buf.ensure((size_t)count * 32, false)) return rc;
+    if (int rc = c->export_buf.ensure((size_t)count * 32, false, c->stream)) return rc;
     const uint2* hits = (c->last_extended && c->hits.p) ? c->hits.as<uint2>() : nullptr;
     launch_export_rays(c->rays.as<float4>(), hits, c->export_buf.p, c->ox, c->oz, first, count, c->stream);
     HIP_TRY(hipGetLastError());
@@ -600,6 +604,18 @@ int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
     }
     *ptr = b->p;
     *bytes = (int64_t)((size_t)c->T * elem);
+    return UVRT_OK;
+}
+
+int uvrt_copy_device(uvrt_ctx* c, int32_t which, void* ext, int32_t to_ctx)
+{
+    void* p = nullptr;
+    int64_t bytes = 0;
+    if (!ext) return fail(UVRT_ERR_INVALID, "uvrt_copy_device: null pointer");
+    if (int rc = uvrt_device_ptr(c, which, &p, &bytes)) return rc;
+    if (int rc = set_device(c)) return rc;
+    if (to_ctx) HIP_TRY(hipMemcpyAsync(p, ext, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(hipMemcpyAsync(ext, p, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
     return UVRT_OK;
 }
 

@@ -1,0 +1,106 @@
+// uvrt_cli.cpp -- headless equivalent of the reference's per-frame compute block
+// (MyApp::Init myapp.cpp:36-39 + MyApp::Tick myapp.cpp:156-175): load the room, Init the
+// RayTracer, ResetDosageMap, then {ComputeDosageMap; Shade; currIterations++; sync; progress
+// line} until maxIterations, and dump the per-triangle dose.
+//
+//   uvrt_cli --room rooms/testroomopt.glb [--route-dir positions/] [--route lange_route]
+//            [--photons N] [--iterations K] [--lamps L] [--view dosage|maxpower]
+//            [--calibrate POWER HEIGHT DIST] [--device D] [--dump dose.f32] [--save-route name]
+#include "raytracer.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+using namespace Tmpl8;
+
+int main(int argc, char** argv)
+{
+    std::string room, routeDir = "positions/", route = "route", dump, saveRoute;
+    long long photons = -1;
+    int iterations = -1, lamps = -1, device = 0;
+    bool calibrate = false;
+    float calP = 2909.0f, calH = 0.8f, calD = 1.0f;   // userinterface.cpp:107-109 defaults
+    ViewMode view = dosage;
+    for (int i = 1; i < argc; ++i) {
+        auto need = [&](int k) { if (i + k >= argc) { fprintf(stderr, "missing value for %s\n", argv[i]); exit(2); } };
+        if (!strcmp(argv[i], "--room")) { need(1); room = argv[++i]; }
+        else if (!strcmp(argv[i], "--route-dir")) { need(1); routeDir = argv[++i]; }
+        else if (!strcmp(argv[i], "--route")) { need(1); route = argv[++i]; }
+        else if (!strcmp(argv[i], "--photons")) { need(1); photons = atoll(argv[++i]); }
+        else if (!strcmp(argv[i], "--iterations")) { need(1); iterations = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--lamps")) { need(1); lamps = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--device")) { need(1); device = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--dump")) { need(1); dump = argv[++i]; }
+        else if (!strcmp(argv[i], "--save-route")) { need(1); saveRoute = argv[++i]; }
+        else if (!strcmp(argv[i], "--view")) { need(1); view = !strcmp(argv[++i], "maxpower") ? maxpower : dosage; }
+        else if (!strcmp(argv[i], "--calibrate")) { need(3); calibrate = true; calP = (float)atof(argv[++i]); calH = (float)atof(argv[++i]); calD = (float)atof(argv[++i]); }
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    if (room.empty()) { fprintf(stderr, "usage: uvrt_cli --room file.glb [options]\n"); return 2; }
+    if (!routeDir.empty() && routeDir.back() != '/') routeDir += '/';
+
+    Mesh mesh;
+    if (!mesh.LoadMeshFromFile(room.c_str())) return 1;
+
+    RayTracer rayTracer;
+    rayTracer.deviceId = device;
+    rayTracer.routeDir = routeDir;
+    rayTracer.autoSaveRoute = false;
+    strncpy(rayTracer.defaultRouteFile, route.c_str(), 31);
+    rayTracer.Init(&mesh);                                   // myapp.cpp:39
+    if (rayTracer.lightPositions.empty()) rayTracer.AddLamp();
+    if (lamps > 0 && lamps < (int)rayTracer.lightPositions.size()) rayTracer.lightPositions.resize(lamps);
+    if (photons > 0) rayTracer.photonCount = (int)photons;
+    if (iterations > 0) rayTracer.maxIterations = iterations;
+    rayTracer.UpdatePhotonsPerLight();
+
+    if (calibrate) {
+        rayTracer.CalibratePower(calP, calH, calD);          // userinterface.cpp:130-133
+        std::cout << "Calibrated lamp power: " << rayTracer.lightIntensity << std::endl;
+    }
+
+    rayTracer.ResetDosageMap();                              // userinterface.cpp:247-251
+    rayTracer.viewMode = view;
+    while (!rayTracer.finishedComputation) {                 // myapp.cpp:156-175
+        rayTracer.finishedComputation = rayTracer.currIterations >= rayTracer.maxIterations;
+        if (rayTracer.finishedComputation) break;
+        rayTracer.ComputeDosageMap();
+        rayTracer.Shade();
+        if (rayTracer.viewMode == texture) rayTracer.viewMode = dosage;
+        rayTracer.currIterations++;
+        rayTracer.progress = 100.0f * static_cast<float>(rayTracer.currIterations) / static_cast<float>(rayTracer.maxIterations);
+        rayTracer.Sync();
+        float time = rayTracer.timerClock.elapsed();
+        rayTracer.compTime += time;
+        std::cout << "Progress: " << rayTracer.progress << "% photon count: " << rayTracer.photonMapSize
+                  << " delta time: " << time * 1000.0f << " total time: " << rayTracer.compTime * 1000.0f << std::endl;
+        rayTracer.timerClock.reset();
+    }
+    const double rays = (double)rayTracer.photonMapSize;
+    std::cout << "Traced " << rays << " photons in " << rayTracer.compTime * 1000.0f << " ms = "
+              << rays / rayTracer.compTime / 1e6 << " Mray/s" << std::endl;
+
+    std::vector<float> dose(mesh.triangleCount);
+    rayTracer.ReadDosage(dose.data(), 0, mesh.triangleCount);
+    double sum = 0;
+    int nonzero = 0;
+    for (float d : dose) { sum += d; nonzero += d != 0.0f; }
+    printf("dose: sum %.6f, %d of %d triangles non-zero, dose[0..3] = %.9g %.9g %.9g %.9g\n", sum, nonzero,
+           mesh.triangleCount, dose[0], dose.size() > 1 ? dose[1] : 0.f, dose.size() > 2 ? dose[2] : 0.f,
+           dose.size() > 3 ? dose[3] : 0.f);
+    if (!dump.empty()) {
+        std::ofstream f(dump, std::ios::binary);
+        f.write((const char*)dose.data(), (std::streamsize)dose.size() * 4);
+    }
+    if (!saveRoute.empty()) {
+        char name[32];
+        strncpy(name, saveRoute.c_str(), 31);
+        name[31] = 0;
+        rayTracer.SaveRoute(name);                           // myapp.cpp:298
+    }
+    return 0;
+}
