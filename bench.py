@@ -38,6 +38,18 @@ def census_path():
     return os.path.join(ROOT, "tests", "golden", "census_lamp0_%d.json" % PHOTONS)
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("UVRT_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(glb, route_xml, waves, photons):
     """The oracle (CPU restatement of the reference kernels, OpenMP on all host cores) timed on
     the same workload: `waves` launches of `photons` photons from lamp 0.  Also returns the
@@ -47,7 +59,7 @@ def cpu_baseline(glb, route_xml, waves, photons):
     import numpy as np
     s = orc.Scene(glb)
     r = orc.load_route(route_xml)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     c = orc.Computation(s, r["lamps"][:1], photons, r["lightHeight"], r["lightLength"], r["lightIntensity"],
                         nthreads=cores)
     c.reset()
@@ -131,6 +143,7 @@ def main():
     reducer = sharding.MapReducer(rt.ctx, device) if world > 1 else None
 
     def step():
+        rt.ctx.seed = 0                       # every step is the same computation (fresh-Init SEED)
         rt.ResetDosageMap()
         rt.set_shard(rank, world)             # restart the global launch index
         for _ in range(rt.maxIterations):     # myapp.cpp:156-163

@@ -45,6 +45,8 @@ struct SceneDev {
 
 struct GenParams {
     float4* rays;          // [n] gid order: dir.xyz, orig.y
+    double* recip;         // [3][capacity] RN64(1/dir) per component, gid order (nullptr: skip)
+    int64_t recip_stride;  // = ray capacity
     uint2* keyrank;        // [n] (key, rank within key) or nullptr when not sorting
     uint32_t* hist;        // [1 << sort_bits]
     float lx, ly, lz;      // lamp position (generate.cl arg 1)
@@ -59,6 +61,10 @@ struct GenParams {
 struct ExtendParams {
     SceneDev scene;
     const float4* rays;      // [n] in trace order
+    const double* recip;     // [3][recip_stride] RN64(1/dir), trace order
+    int64_t recip_stride;
+    uint32_t* ray_counter;   // persistent kernel: next unclaimed trace slot (zeroed per launch)
+    int32_t force_exact;     // scene or lamp position outside the fast path's proof conditions
     const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)
     uint2* hits;             // [n] by local ray index: (dist bits, triID), or nullptr
     int32_t* counts;         // tempPhotonMap
@@ -71,7 +77,8 @@ struct ExtendParams {
 void launch_generate(const GenParams& p, hipStream_t s);
 void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStream_t s);
 void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bin_start,
-                    float4* sorted, uint32_t* order, int64_t n, hipStream_t s);
+                    float4* sorted, uint32_t* order, double* recip_sorted, int64_t recip_stride,
+                    int64_t n, hipStream_t s);
 void launch_extend(const ExtendParams& p, int variant, hipStream_t s);
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, float time_step,
                        int32_t T, hipStream_t s);
