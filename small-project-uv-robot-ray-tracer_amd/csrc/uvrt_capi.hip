@@ -70,6 +70,8 @@ struct uvrt_ctx {
     DevBuf pairs, ltris, leaf_count, area;
     uint32_t root_ref = REF_DONE;
     bool have_scene = false;
+    int32_t replicas = 1;        // deposit replicas of tempPhotonMap (uvrt_device.h ExtendParams)
+    int32_t replicas_knob = -1;  // -1: choose from T
 
     // per-triangle maps (raytracer.cpp:32-37)
     DevBuf photon_map, max_map, counts, dosage, color;
@@ -77,6 +79,8 @@ struct uvrt_ctx {
     // rays
     int64_t capacity = 0;
     DevBuf rays, keyrank, sorted, order, hits, hist, bin_start, export_buf;
+    DevBuf recip, recip_sorted, ray_counter, ovf_stack;   // f64 reciprocals [3][capacity]; persistent-kernel cursor
+    bool scene_force_exact = false;            // a node bound too tiny for the reciprocal shortcut
     int32_t hist_bins = 0;
     int64_t last_n = -1;
     int64_t last_first = 0;
@@ -169,6 +173,9 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
+    if (!rc) rc = c->ray_counter.ensure(sizeof(uint32_t), true, c->stream);
+    // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
+    if (!rc) rc = c->ovf_stack.ensure((size_t)256 * 16 * 256 * 16 * sizeof(uint32_t), false, c->stream);
     if (rc) { delete c; return rc; }
     *out = c;
     return UVRT_OK;
@@ -182,7 +189,7 @@ void uvrt_destroy(uvrt_ctx* c)
     for (DevBuf* b : {&c->pairs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
-                      &c->error_flag})
+                      &c->recip, &c->recip_sorted, &c->ray_counter, &c->ovf_stack, &c->error_flag})
         b->release();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -227,6 +234,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     std::vector<PairRec> pairs;
     std::vector<int32_t> queue;   // inner nodes in BFS order; index in queue == pair index
     int err = 0;
+    bool tiny_bound = false;
     uint32_t root_ref;
     if (nodes[0].triCount > 0) {
         root_ref = leaf_ref(nodes[0], leaf_count, err);
@@ -247,6 +255,10 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         }
         const HostNode& a = nodes[l];
         const HostNode& b = nodes[l + 1];
+        for (const HostNode* hn : {&a, &b})
+            for (int k = 0; k < 3; ++k)
+                for (float v : {hn->mn[k], hn->mx[k]})
+                    if (v != 0.0f && std::fabs(v) < 8.6736174e-19f) tiny_bound = true;   // 2^-60
         PairRec pr;
         pr.c0min_ref0 = make_float4(a.mn[0], a.mn[1], a.mn[2], 0.f);
         pr.c0max_ref1 = make_float4(a.mx[0], a.mx[1], a.mx[2], 0.f);
@@ -271,7 +283,11 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->dosage, &c->color}) b->release();
         if ((rc = c->photon_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         if ((rc = c->max_map.ensure((size_t)T * 8, true, c->stream))) return rc;
-        if ((rc = c->counts.ensure((size_t)T * 4, true, c->stream))) return rc;
+        // up to 64 deposit replicas, at most 64 MiB in total
+        int R = c->replicas_knob > 0 ? c->replicas_knob : 64;
+        while (R > 1 && (size_t)R * (size_t)T * 4 > ((size_t)64 << 20)) R >>= 1;
+        c->replicas = R;
+        if ((rc = c->counts.ensure((size_t)R * (size_t)T * 4, true, c->stream))) return rc;
         if ((rc = c->dosage.ensure((size_t)T * 4, true, c->stream))) return rc;
         if ((rc = c->color.ensure((size_t)T * 36, true, c->stream))) return rc;
     }
@@ -297,6 +313,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->T = T;
     c->root_ref = root_ref;
     c->have_scene = true;
+    c->scene_force_exact = tiny_bound;
     return UVRT_OK;
 }
 
@@ -312,6 +329,8 @@ int uvrt_resize_rays(uvrt_ctx* c, int64_t photon_count)
     if ((rc = c->keyrank.ensure(n * 8, false, c->stream))) return rc;
     if ((rc = c->sorted.ensure(n * 16, false, c->stream))) return rc;
     if ((rc = c->order.ensure(n * 4, false, c->stream))) return rc;
+    if ((rc = c->recip.ensure(n * 24, false, c->stream))) return rc;
+    if ((rc = c->recip_sorted.ensure(n * 24, false, c->stream))) return rc;
     if (c->record_hits && (rc = c->hits.ensure(n * 8, false, c->stream))) return rc;
     c->capacity = photon_count;
     c->last_n = -1;
@@ -323,7 +342,7 @@ int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
     if (!c || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_reset: no scene");
     if (int rc = set_device(c)) return rc;
     launch_reset(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
-                 c->color.as<float>(), reset_color, c->T, c->stream);
+                 c->replicas, c->T, c->color.as<float>(), reset_color, c->T, c->stream);
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -367,6 +386,8 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     GenParams p;
     memset(&p, 0, sizeof p);
     p.rays = c->rays.as<float4>();
+    p.recip = c->recip.as<double>();
+    p.recip_stride = c->capacity;
     p.lx = lp[0]; p.ly = lp[1]; p.lz = lp[2];
     p.light_length = light_length;
     p.first_gid = first_gid;
@@ -393,7 +414,8 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (p.keyrank) {
         launch_scan_bins(c->hist.as<uint32_t>(), c->bin_start.as<uint32_t>(), 1 << bits, c->stream);
         launch_scatter(c->rays.as<float4>(), c->keyrank.as<uint2>(), c->bin_start.as<uint32_t>(),
-                       c->sorted.as<float4>(), c->order.as<uint32_t>(), n, c->stream);
+                       c->sorted.as<float4>(), c->order.as<uint32_t>(), c->recip_sorted.as<double>(),
+                       c->capacity, n, c->stream);
         HIP_TRY(hipGetLastError());
     }
     c->seed = seed_next;
@@ -424,9 +446,20 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.scene.root_ref = c->root_ref;
     p.scene.tri_count = c->T;
     p.rays = c->last_sorted ? c->sorted.as<float4>() : c->rays.as<float4>();
+    p.recip = c->last_sorted ? c->recip_sorted.as<double>() : c->recip.as<double>();
+    p.recip_stride = c->capacity;
+    {
+        // conditions of the reciprocal shortcut that are uniform over the launch (slab<>())
+        const float ax = std::fabs(c->ox), az = std::fabs(c->oz);
+        const float tiny = 7.888609e-31f;   // 2^-100
+        p.force_exact = (c->scene_force_exact || (ax != 0.0f && ax < tiny) || (az != 0.0f && az < tiny)) ? 1 : 0;
+    }
     p.order = c->last_sorted ? c->order.as<uint32_t>() : nullptr;
     p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
+    p.ovf_stack = c->ovf_stack.as<uint32_t>();
     p.counts = c->counts.as<int32_t>();
+    p.count_replicas = c->replicas;
+    p.count_stride = c->T;
     p.error_flag = c->error_flag.as<uint32_t>();
     p.ox = c->ox;
     p.oz = c->oz;
@@ -457,7 +490,7 @@ int uvrt_accumulate(uvrt_ctx* c, float time_step, int32_t tri_count)
         return fail(UVRT_ERR_INVALID, "uvrt_accumulate: bad tri_count");
     if (int rc = set_device(c)) return rc;
     launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
-                      time_step, tri_count, c->stream);
+                      c->replicas, c->T, time_step, tri_count, c->stream);
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -526,6 +559,10 @@ int uvrt_read_color(uvrt_ctx* c, float* out9, int32_t first, int32_t count)
 }
 int uvrt_read_counts(uvrt_ctx* c, int32_t* out, int32_t first, int32_t count)
 {
+    if (c && c->have_scene) {
+        if (int rc = set_device(c)) return rc;
+        launch_fold_counts(c->counts.as<int32_t>(), c->replicas, c->T, c->T, c->stream);
+    }
     return read_back(c, c ? c->counts : DevBuf(), 4, out, first, count, c ? c->T : 0, "uvrt_read_counts");
 }
 int uvrt_read_photon_map(uvrt_ctx* c, int32_t which, double* out, int32_t first, int32_t count)
@@ -597,7 +634,11 @@ int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
     switch (which) {
         case 0: b = &c->photon_map; elem = 8; break;
         case 1: b = &c->max_map; elem = 8; break;
-        case 2: b = &c->counts; elem = 4; break;
+        case 2:
+            b = &c->counts; elem = 4;
+            if (int rc = set_device(c)) return rc;
+            launch_fold_counts(c->counts.as<int32_t>(), c->replicas, c->T, c->T, c->stream);
+            break;
         case 3: b = &c->dosage; elem = 4; break;
         case 4: b = &c->color; elem = 36; break;
         default: return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: which must be 0..4");

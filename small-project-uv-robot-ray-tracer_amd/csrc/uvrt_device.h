@@ -63,11 +63,16 @@ struct ExtendParams {
     const float4* rays;      // [n] in trace order
     const double* recip;     // [3][recip_stride] RN64(1/dir), trace order
     int64_t recip_stride;
-    uint32_t* ray_counter;   // persistent kernel: next unclaimed trace slot (zeroed per launch)
+    uint32_t chunk;          // persistent kernel: trace slots owned by each wavefront
+    uint32_t* ovf_stack;     // persistent kernel: [grid threads][16] traversal-stack overflow
     int32_t force_exact;     // scene or lamp position outside the fast path's proof conditions
     const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)
     uint2* hits;             // [n] by local ray index: (dist bits, triID), or nullptr
-    int32_t* counts;         // tempPhotonMap
+    int32_t* counts;         // tempPhotonMap, count_replicas copies count_stride ints apart: a
+                             // workgroup deposits into copy (blockIdx % count_replicas), so hits on
+                             // a hot triangle do not serialise on one address; accumulate folds them
+    int32_t count_replicas;
+    int64_t count_stride;
     uint32_t* error_flag;    // set to 1 on traversal stack overflow
     float ox, oz;            // launch-uniform origin components
     int64_t n;
@@ -80,10 +85,11 @@ void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bi
                     float4* sorted, uint32_t* order, double* recip_sorted, int64_t recip_stride,
                     int64_t n, hipStream_t s);
 void launch_extend(const ExtendParams& p, int variant, hipStream_t s);
-void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, float time_step,
-                       int32_t T, hipStream_t s);
-void launch_reset(double* photon_map, double* max_map, int32_t* counts, float* color,
-                  int32_t reset_color, int32_t T, hipStream_t s);
+void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,
+                       int64_t stride, float time_step, int32_t T, hipStream_t s);
+void launch_reset(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,
+                  int64_t stride, float* color, int32_t reset_color, int32_t T, hipStream_t s);
+void launch_fold_counts(int32_t* counts, int32_t replicas, int64_t stride, int32_t T, hipStream_t s);
 void launch_compute_dosage(const double* map, float* dosage, const float* area,
                            int32_t photons_per_light, float scaled_power, int32_t T,
                            hipStream_t s);

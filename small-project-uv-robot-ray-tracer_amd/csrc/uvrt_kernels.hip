@@ -83,6 +83,11 @@ __global__ __launch_bounds__(256) void k_generate(GenParams p)
     const float dirx = (float)(x * s);
     const float dirz = (float)(y * s);
     p.rays[i] = make_float4(dirx, diry, dirz, origy);                     // :31-37
+    if (p.recip) {   // RN64(1/dir): the slab test's exact-division shortcut (see slab<>())
+        p.recip[i] = 1.0 / (double)dirx;
+        p.recip[p.recip_stride + i] = 1.0 / (double)diry;
+        p.recip[2 * p.recip_stride + i] = 1.0 / (double)dirz;
+    }
 
     if (p.keyrank) {
         // azimuth as a diamond angle in [0,4): monotone in the true angle, one division
@@ -132,14 +137,22 @@ __global__ __launch_bounds__(256) void k_scatter(const float4* __restrict__ rays
                                                  const uint2* __restrict__ keyrank,
                                                  const uint32_t* __restrict__ bin_start,
                                                  float4* __restrict__ sorted,
-                                                 uint32_t* __restrict__ order, int64_t n)
+                                                 uint32_t* __restrict__ order,
+                                                 double* __restrict__ recip, int64_t recip_stride,
+                                                 int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint2 kr = keyrank[i];
     const uint32_t pos = bin_start[kr.x] + kr.y;
-    sorted[pos] = rays[i];
+    const float4 r = rays[i];
+    sorted[pos] = r;
     order[pos] = (uint32_t)i;
+    if (recip) {
+        recip[pos] = 1.0 / (double)r.x;
+        recip[recip_stride + pos] = 1.0 / (double)r.y;
+        recip[2 * recip_stride + pos] = 1.0 / (double)r.z;
+    }
 }
 
 // ------------------------------------------------------------------- extend, cl/extend.cl
@@ -228,7 +241,11 @@ __device__ __forceinline__ void bvh_intersect(RayRegs& r, const SceneDev& sc,
 #define UVRT_POP()                                                                     \
     do {                                                                               \
         if (sp == 0) cur = REF_DONE;                                                   \
-        else { --sp; cur = sp < LDS_STACK ? s_stack[sp][tid] : ovf[sp - LDS_STACK]; }  \
+        else {                                                                         \
+            --sp;                                                                      \
+            if (sp < LDS_STACK) { cur = s_stack[sp][tid]; asm volatile("" : "+v"(cur)); } \
+            else cur = ovf[sp - LDS_STACK];                                            \
+        }                                                                              \
     } while (0)
 
     while (cur != REF_DONE) {
@@ -284,38 +301,253 @@ __global__ __launch_bounds__(256) void k_extend(ExtendParams p)
         const uint32_t li = p.order ? p.order[i] : (uint32_t)i;
         p.hits[li] = make_uint2(__float_as_uint(r.dist), r.triID);
     }
-    if (r.dist != 1e30f) atomicAdd(&p.counts[r.triID], 1);   // extend.cl:94-98
+    if (r.dist != 1e30f)                                     // extend.cl:94-98
+        atomicAdd(&p.counts[(int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride + r.triID], 1);
+}
+
+
+// ----------------------------------------------------------------------------------------
+// extend v2: persistent wavefronts, one traversal step per loop trip, idle lanes refilled from
+// a global ray counter, and the slab divisions taken through a precomputed f64 reciprocal.
+//
+// slab<EXACT=false>:  (float)((double)(b - o) * r)  with  r = RN64(1 / (double)d)
+// equals the IEEE binary32 quotient  RN32((b - o) / d)  bit for bit.  Proof sketch (DESIGN.md
+// "Exact division by reciprocal"): let a = RN32(b - o).  (i) The f64 product is (a/d)(1+e),
+// |e| <= 2^-52.  (ii) For binary32 a, d the exact quotient a/d is never closer than 2^-49
+// (relative) to a rounding boundary of binary32 -- a midpoint M*2^k with M odd in (2^24,2^25),
+// or the overflow threshold -- unless it is far into the subnormal range: a - M*2^k*d is a
+// non-zero integer multiple of 2^(k + exponent(d)), and |d| < 2^24 ulps.  Hence the product and
+// the quotient lie on the same side of every boundary and round to the same float.  (iii) The
+// quotient is normal-or-zero whenever |d| <= 1 and a is zero or |a| >= 2^-100; lanes or scenes
+// outside these conditions (zero / >1 direction component, tiny origin or bound) take
+// slab<true>, the reference's own division, as do NaN-producing rays (0/0).  +-inf from d = 0
+// never reaches this path.
+template <bool EXACT>
+__device__ __forceinline__ float slab(float b, float o, float d, double r)
+{
+    if (EXACT) return (b - o) / d;
+    return (float)((double)(b - o) * r);
+}
+
+struct RayState {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    double rx, ry, rz;
+    float dist;
+    uint32_t triID;
+};
+
+template <bool EXACT>
+__device__ __forceinline__ float intersect_aabb2(const RayState& r, float mnx, float mny, float mnz,
+                                                 float mxx, float mxy, float mxz)
+{
+    const float tx1 = slab<EXACT>(mnx, r.ox, r.dx, r.rx), tx2 = slab<EXACT>(mxx, r.ox, r.dx, r.rx);
+    float tmin = cl_min<EXACT>(tx1, tx2), tmax = cl_max<EXACT>(tx1, tx2);
+    const float ty1 = slab<EXACT>(mny, r.oy, r.dy, r.ry), ty2 = slab<EXACT>(mxy, r.oy, r.dy, r.ry);
+    tmin = cl_max<EXACT>(tmin, cl_min<EXACT>(ty1, ty2));
+    tmax = cl_min<EXACT>(tmax, cl_max<EXACT>(ty1, ty2));
+    const float tz1 = slab<EXACT>(mnz, r.oz, r.dz, r.rz), tz2 = slab<EXACT>(mxz, r.oz, r.dz, r.rz);
+    tmin = cl_max<EXACT>(tmin, cl_min<EXACT>(tz1, tz2));
+    tmax = cl_min<EXACT>(tmax, cl_max<EXACT>(tz1, tz2));
+    if (tmax >= tmin && tmin < r.dist && tmax > 0) return tmin;
+    return 1e30f;
+}
+
+__device__ __forceinline__ void intersect_tri2(RayState& r, const LeafTri* __restrict__ t)
+{
+    const float4 v0 = t->v0_id, e1 = t->e1, e2 = t->e2;
+    const float hx = r.dy * e2.z - r.dz * e2.y;
+    const float hy = r.dz * e2.x - r.dx * e2.z;
+    const float hz = r.dx * e2.y - r.dy * e2.x;
+    const float a = e1.x * hx + e1.y * hy + e1.z * hz;
+    if (fabsf(a) < 0.00001f) return;
+    const float f = 1.0f / a;
+    const float sx = r.ox - v0.x, sy = r.oy - v0.y, sz = r.oz - v0.z;
+    const float u = f * (sx * hx + sy * hy + sz * hz);
+    if ((u < 0) | (u > 1)) return;
+    const float qx = sy * e1.z - sz * e1.y;
+    const float qy = sz * e1.x - sx * e1.z;
+    const float qz = sx * e1.y - sy * e1.x;
+    const float v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
+    if ((v < 0) | (u + v > 1)) return;
+    const float tt = f * (e2.x * qx + e2.y * qy + e2.z * qz);
+    if (tt > 0.0001f && tt < r.dist) {
+        r.dist = tt;
+        r.triID = __float_as_uint(v0.w);
+    }
+}
+
+// One traversal step of one lane (extend.cl:44-80): an inner node (test both children, order
+// them, descend / push / pop) or a leaf (test its triangles, pop).
+template <bool EXACT>
+__device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& sp, uint32_t* ovf,
+                                               const SceneDev& sc, uint32_t (*s_stack)[256],
+                                               uint32_t* error_flag)
+{
+    const int tid = threadIdx.x;
+    bool pop = false;
+    if (cur < REF_LEAF_BIT) {
+        const PairRec* pr = sc.pairs + cur;
+        const float4 a = pr->c0min_ref0, b = pr->c0max_ref1, c = pr->c1min, d = pr->c1max;
+        float dist1 = intersect_aabb2<EXACT>(r, a.x, a.y, a.z, b.x, b.y, b.z);
+        float dist2 = intersect_aabb2<EXACT>(r, c.x, c.y, c.z, d.x, d.y, d.z);
+        uint32_t ref1 = __float_as_uint(a.w), ref2 = __float_as_uint(b.w);
+        if (dist1 > dist2) {
+            const float td = dist1; dist1 = dist2; dist2 = td;
+            const uint32_t tr = ref1; ref1 = ref2; ref2 = tr;
+        }
+        if (dist1 == 1e30f) pop = true;
+        else {
+            cur = ref1;
+            if (dist2 != 1e30f) {
+                if (sp < LDS_STACK) s_stack[sp][tid] = ref2;
+                else if (sp < MAX_STACK) ovf[sp - LDS_STACK] = ref2;
+                else *error_flag = 1u;
+                if (sp < MAX_STACK) ++sp;
+            }
+        }
+    } else if (cur != REF_DONE) {
+        const uint32_t first = cur & REF_FIRST_MASK;
+        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
+        if (count == 15u) count = sc.leaf_count[first];
+        for (uint32_t i = 0; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
+        pop = true;
+    }
+    if (pop) {
+        if (sp == 0) cur = REF_DONE;
+        else {
+            --sp;
+            if (sp < LDS_STACK) {
+                cur = s_stack[sp][tid];
+                asm volatile("" : "+v"(cur));   // keeps this a ds_read (no flat load through a
+            } else {                            // pointer selected between LDS and scratch)
+                cur = ovf[sp - LDS_STACK];
+            }
+        }
+    }
+}
+
+// Persistent wavefronts over statically owned ray chunks.  Wave w of the grid owns the trace
+// slots [w*chunk, (w+1)*chunk); lanes that finish a ray take the next unclaimed slot of their own
+// wave's chunk (a wave-uniform cursor: no atomics, no inter-wave traffic), REFILL_MIN idle lanes
+// at a time, so the 64 lanes stay busy although ray lengths differ by an order of magnitude.
+template <int REFILL_MIN>
+__global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
+{
+    __shared__ uint32_t s_stack[LDS_STACK][256];
+    // stack entries 16..31 of this thread (never touched on sane trees) live in global memory
+    uint32_t* const ovf = p.ovf_stack + ((size_t)blockIdx.x * 256 + threadIdx.x) * (MAX_STACK - LDS_STACK);
+    RayState r;
+    r.ox = p.ox; r.oz = p.oz;
+    r.oy = 0.f; r.dx = r.dy = r.dz = 1.f; r.rx = r.ry = r.rz = 1.0; r.dist = 1e30f; r.triID = 0;
+    uint32_t cur = REF_DONE;   // this lane holds no ray
+    uint32_t slot = 0;         // trace slot of the ray held
+    int sp = 0;
+    bool live = false;         // holds a ray whose result has not been deposited yet
+    bool special = false;      // this lane's ray needs the EXACT path
+    int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
+
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t cursor = __builtin_amdgcn_readfirstlane(min((uint64_t)wave * p.chunk, (uint64_t)p.n));
+    const uint32_t chunk_end = __builtin_amdgcn_readfirstlane(min((uint64_t)(wave + 1) * p.chunk, (uint64_t)p.n));
+
+    for (;;) {
+        const bool idle = cur == REF_DONE;
+        const unsigned long long idle_mask = __ballot(idle);
+        const int nidle = __popcll(idle_mask);
+        if (cursor < chunk_end && nidle >= REFILL_MIN) {
+            if (idle) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const uint32_t my = cursor + rank;
+                if (my < chunk_end) {
+                    const float4 rec = p.rays[my];
+                    r.dx = rec.x; r.dy = rec.y; r.dz = rec.z; r.oy = rec.w;
+                    r.rx = p.recip[my];
+                    r.ry = p.recip[p.recip_stride + my];
+                    r.rz = p.recip[2 * p.recip_stride + my];
+                    r.dist = 1e30f;                        // generate.cl:34-35
+                    r.triID = 0;
+                    slot = my;
+                    sp = 0;
+                    cur = p.scene.root_ref;
+                    live = true;
+                    const float ay = fabsf(r.oy);
+                    special = r.dx == 0.0f || r.dy == 0.0f || r.dz == 0.0f ||
+                              !(fabsf(r.dx) <= 1.0f) || !(fabsf(r.dy) <= 1.0f) || !(fabsf(r.dz) <= 1.0f) ||
+                              (ay != 0.0f && ay < 7.888609e-31f) || p.force_exact != 0;
+                }
+            }
+            cursor += (uint32_t)nidle;
+        }
+        const bool active = cur != REF_DONE;
+        if (!__any(active)) {
+            if (cursor >= chunk_end) break;
+            continue;
+        }
+        if (__any(active & special))
+            traversal_step<true>(r, cur, sp, ovf, p.scene, s_stack, p.error_flag);
+        else
+            traversal_step<false>(r, cur, sp, ovf, p.scene, s_stack, p.error_flag);
+
+        if (live && cur == REF_DONE) {                     // ray finished this trip: deposit
+            live = false;
+            if (p.hits) {
+                const uint32_t li = p.order ? p.order[slot] : slot;
+                p.hits[li] = make_uint2(__float_as_uint(r.dist), r.triID);
+            }
+            if (r.dist != 1e30f) atomicAdd(&my_counts[r.triID], 1);   // extend.cl:94-98
+        }
+    }
 }
 
 // ----------------------------------------------------------- per-triangle kernels (O(T))
 
-// accumulate.cl:4-14
+// accumulate.cl:4-14; tempPhotonMap[i] is the (exact, integer) sum of the deposit replicas
 __global__ __launch_bounds__(256) void k_accumulate(double* __restrict__ photon_map,
                                                     double* __restrict__ max_map,
-                                                    int32_t* __restrict__ counts,
-                                                    float time_step, int32_t T)
+                                                    int32_t* __restrict__ counts, int32_t replicas,
+                                                    int64_t stride, float time_step, int32_t T)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= T) return;
-    const double c = (double)counts[i];
+    int32_t total = 0;
+    for (int r = 0; r < replicas; ++r) {
+        total += counts[r * stride + i];
+        counts[r * stride + i] = 0;
+    }
+    const double c = (double)total;
     photon_map[i] = photon_map[i] + c * (double)time_step;
     const double m = max_map[i];
     max_map[i] = m < c ? c : m;
-    counts[i] = 0;
+}
+
+// tempPhotonMap in the reference's single-array form: replica 0 = sum, the others zero
+__global__ __launch_bounds__(256) void k_fold_counts(int32_t* __restrict__ counts, int32_t replicas,
+                                                     int64_t stride, int32_t T)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    int32_t total = counts[i];
+    for (int r = 1; r < replicas; ++r) {
+        total += counts[r * stride + i];
+        counts[r * stride + i] = 0;
+    }
+    counts[i] = total;
 }
 
 // reset.cl:4-26
 __global__ __launch_bounds__(256) void k_reset(double* __restrict__ photon_map,
                                                double* __restrict__ max_map,
-                                               int32_t* __restrict__ counts,
-                                               float* __restrict__ color, int32_t reset_color,
-                                               int32_t T)
+                                               int32_t* __restrict__ counts, int32_t replicas,
+                                               int64_t stride, float* __restrict__ color,
+                                               int32_t reset_color, int32_t T)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= T) return;
     photon_map[i] = 0;
     max_map[i] = 0;
-    counts[i] = 0;
+    for (int r = 0; r < replicas; ++r) counts[r * stride + i] = 0;
     if (!reset_color) return;
     for (int k = 0; k < 9; ++k) color[(int64_t)i * 9 + k] = 0.0f;
 }
@@ -439,34 +671,62 @@ void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStr
 }
 
 void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bin_start,
-                    float4* sorted, uint32_t* order, int64_t n, hipStream_t s)
+                    float4* sorted, uint32_t* order, double* recip_sorted, int64_t recip_stride,
+                    int64_t n, hipStream_t s)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, s, rays, keyrank,
-                       bin_start, sorted, order, n);
+                       bin_start, sorted, order, recip_sorted, recip_stride, n);
 }
 
-void launch_extend(const ExtendParams& p, int variant, hipStream_t s)
+// variant = threshold code + 10 * grid code.  Threshold code: 0 default, 1 = v1 kernel (one ray
+// per lane, IEEE divisions, no refill), 2/3/4/5/6 = refill when >= 1/8/16/32/64 lanes are idle.
+// Grid code: workgroups per CU = 8 (0), 4 (1), 6 (2), 2 (3), 16 (4).
+void launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
 {
-    (void)variant;
-    if (p.n <= 0) return;
-    hipLaunchKernelGGL(k_extend, dim3(blocks_for(p.n, 256)), dim3(256), 0, s, p);
+    if (p0.n <= 0) return;
+    ExtendParams p = p0;
+    const int tcode = variant % 10, gcode = (variant / 10) % 10;
+    if (tcode == 1) {
+        hipLaunchKernelGGL(k_extend, dim3(blocks_for(p.n, 256)), dim3(256), 0, s, p);
+        return;
+    }
+    static const unsigned per_cu[5] = {8, 4, 6, 2, 16};
+    unsigned grid = 256u * per_cu[gcode < 5 ? gcode : 0];
+    const unsigned need = blocks_for(p.n, 256);
+    if (need < grid) grid = need;
+    const uint64_t waves = (uint64_t)grid * 4;
+    p.chunk = (uint32_t)((((uint64_t)p.n + waves - 1) / waves + 63) / 64 * 64);   // whole batches of 64
+    switch (tcode) {
+        case 2: hipLaunchKernelGGL(k_extend_persist<1>, dim3(grid), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(k_extend_persist<8>, dim3(grid), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL(k_extend_persist<32>, dim3(grid), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL(k_extend_persist<64>, dim3(grid), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(k_extend_persist<16>, dim3(grid), dim3(256), 0, s, p); break;
+    }
 }
 
-void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, float time_step,
-                       int32_t T, hipStream_t s)
+void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,
+                       int64_t stride, float time_step, int32_t T, hipStream_t s)
 {
     if (T <= 0) return;
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(T, 256)), dim3(256), 0, s, photon_map,
-                       max_map, counts, time_step, T);
+                       max_map, counts, replicas, stride, time_step, T);
 }
 
-void launch_reset(double* photon_map, double* max_map, int32_t* counts, float* color,
-                  int32_t reset_color, int32_t T, hipStream_t s)
+void launch_fold_counts(int32_t* counts, int32_t replicas, int64_t stride, int32_t T, hipStream_t s)
+{
+    if (T <= 0 || replicas <= 1) return;
+    hipLaunchKernelGGL(k_fold_counts, dim3(blocks_for(T, 256)), dim3(256), 0, s, counts, replicas,
+                       stride, T);
+}
+
+void launch_reset(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,
+                  int64_t stride, float* color, int32_t reset_color, int32_t T, hipStream_t s)
 {
     if (T <= 0) return;
     hipLaunchKernelGGL(k_reset, dim3(blocks_for(T, 256)), dim3(256), 0, s, photon_map, max_map,
-                       counts, color, reset_color, T);
+                       counts, replicas, stride, color, reset_color, T);
 }
 
 void launch_compute_dosage(const double* map, float* dosage, const float* area,
