@@ -300,3 +300,78 @@ class Computation:
     def max_power(self):                                   # raytracer.cpp:96-104
         return compute_dosage(self.maxPhotonMap, self.s.tris, self.photonsPerLight,
                               np.float32(self.lightIntensity * np.float32(100.0)))
+
+
+# ------------------------------------------------ the reference's own kernels on the GPU
+
+_REFGPU = None
+
+
+def refgpu():
+    """oracle/_ref/ref_*.co (the reference's cl/*.cl compiled unmodified for gfx950) behind
+    oracle/ref_gpu.cpp.  Returns None when the code objects were not built (they are built by
+    `make -C oracle ref` where /root/reference exists and travel to the GPU box prebuilt)."""
+    global _REFGPU
+    if _REFGPU is None:
+        d = os.path.join(_HERE, "_ref")
+        so = os.path.join(_HERE, "libref_gpu.so")
+        if not os.path.exists(os.path.join(d, "ref_extend.co")):
+            return None
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libref_gpu.so"])
+        L = C.CDLL(so)
+        L.refgpu_last_error.restype = C.c_char_p
+        L.refgpu_load.argtypes = [C.c_char_p]
+        L.refgpu_extend.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        L.refgpu_generate.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_float,
+                                      C.POINTER(C.c_double)]
+        L.refgpu_shade.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
+                                   C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+        if L.refgpu_load(os.fsencode(d)) != 0:
+            raise RuntimeError("refgpu_load: " + L.refgpu_last_error().decode())
+        _REFGPU = L
+    return _REFGPU
+
+
+def refgpu_extend(rays, tris, nodes, triIdx, reps=1):
+    """extend.cl:render of the reference on the GPU.  rays (RAY_DT, len % 256 == 0) is updated in
+    place; returns (counts, kernel_ms)."""
+    L = refgpu()
+    assert rays.size % 256 == 0
+    counts = np.zeros(tris.shape[0], dtype=np.int32)
+    ms = C.c_double()
+    if L.refgpu_extend(_p(rays), rays.size, _p(tris), tris.shape[0], _p(nodes), nodes.shape[0], _p(triIdx),
+                       _p(counts), C.byref(ms), int(reps)) != 0:
+        raise RuntimeError("refgpu_extend: " + L.refgpu_last_error().decode())
+    return counts, float(ms.value)
+
+
+def refgpu_generate_ms(n, lp, lightLength):
+    L = refgpu()
+    ms = C.c_double()
+    if L.refgpu_generate(None, int(n), _f3(lp), float(np.float32(lightLength)), C.byref(ms)) != 0:
+        raise RuntimeError("refgpu_generate: " + L.refgpu_last_error().decode())
+    return float(ms.value)
+
+
+def refgpu_shade(photonMap, maxPhotonMap, temp, timeStep, tris, photonsPerLight, scaledPower, minValue,
+                 thresholdView):
+    """accumulate.cl, shade.cl:computeDosage, shade.cl:dosageToColor of the reference on the GPU.
+    Arrays are padded to a multiple of 256 triangles internally.  Returns (dose, color)."""
+    L = refgpu()
+    T = temp.size
+    Tp = (T + 255) // 256 * 256
+    pm = np.zeros(Tp); pm[:T] = photonMap
+    mm = np.zeros(Tp); mm[:T] = maxPhotonMap
+    tc = np.zeros(Tp, dtype=np.int32); tc[:T] = temp
+    tt = np.zeros((Tp, 16), dtype=np.float32); tt[:T] = tris
+    tt[T:, 0] = 1.0; tt[T:, 5] = 1.0          # unit right triangles in the padding (non-zero area)
+    dose = np.zeros(Tp, dtype=np.float32)
+    col = np.zeros((Tp, 9), dtype=np.float32)
+    if L.refgpu_shade(_p(pm), _p(mm), _p(tc), float(np.float32(timeStep)), _p(tt), Tp, int(photonsPerLight),
+                      float(np.float32(scaledPower)), float(np.float32(minValue)), int(bool(thresholdView)),
+                      _p(dose), _p(col)) != 0:
+        raise RuntimeError("refgpu_shade: " + L.refgpu_last_error().decode())
+    photonMap[:] = pm[:T]; maxPhotonMap[:] = mm[:T]; temp[:] = tc[:T]
+    return dose[:T].copy(), col[:T].copy()

@@ -175,7 +175,7 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
     if (!rc) rc = c->ray_counter.ensure(sizeof(uint32_t), true, c->stream);
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
-    if (!rc) rc = c->ovf_stack.ensure((size_t)256 * 16 * 256 * 16 * sizeof(uint32_t), false, c->stream);
+    if (!rc) rc = c->ovf_stack.ensure((size_t)OVF_MAX_ENTRIES * sizeof(uint32_t), false, c->stream);
     if (rc) { delete c; return rc; }
     *out = c;
     return UVRT_OK;
@@ -457,6 +457,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.order = c->last_sorted ? c->order.as<uint32_t>() : nullptr;
     p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
     p.ovf_stack = c->ovf_stack.as<uint32_t>();
+    p.ovf_capacity = c->ovf_stack.bytes / sizeof(uint32_t);
     p.counts = c->counts.as<int32_t>();
     p.count_replicas = c->replicas;
     p.count_stride = c->T;
@@ -477,7 +478,9 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         ++c->ev_used;
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    launch_extend(p, c->variant, c->stream);
+    if (c->variant >= 100) p.force_exact = 1;   // experiment: IEEE divisions everywhere
+    if (!launch_extend(p, c->variant % 100, c->stream))
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
     c->last_extended = c->record_hits;

@@ -64,7 +64,8 @@ struct ExtendParams {
     const double* recip;     // [3][recip_stride] RN64(1/dir), trace order
     int64_t recip_stride;
     uint32_t chunk;          // persistent kernel: trace slots owned by each wavefront
-    uint32_t* ovf_stack;     // persistent kernel: [grid threads][16] traversal-stack overflow
+    uint32_t* ovf_stack;     // persistent kernels: [grid threads][MAX_STACK - LDS entries] stack overflow
+    uint64_t ovf_capacity;   // entries (uint32) available in ovf_stack; launches that need more are refused
     int32_t force_exact;     // scene or lamp position outside the fast path's proof conditions
     const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)
     uint2* hits;             // [n] by local ray index: (dist bits, triID), or nullptr
@@ -84,7 +85,9 @@ void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStr
 void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bin_start,
                     float4* sorted, uint32_t* order, double* recip_sorted, int64_t recip_stride,
                     int64_t n, hipStream_t s);
-void launch_extend(const ExtendParams& p, int variant, hipStream_t s);
+// returns false (nothing launched) when the variant's grid would not fit the overflow-stack buffer
+bool launch_extend(const ExtendParams& p, int variant, hipStream_t s);
+constexpr uint64_t OVF_MAX_ENTRIES = (uint64_t)256 * 16 * 256 * 24;   // largest grid x deepest overflow
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,
                        int64_t stride, float time_step, int32_t T, hipStream_t s);
 void launch_reset(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,

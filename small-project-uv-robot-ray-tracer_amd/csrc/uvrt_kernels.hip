@@ -447,9 +447,15 @@ __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
     bool special = false;      // this lane's ray needs the EXACT path
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
 
+    // Wave w traces the 64-ray batches w, w + W, w + 2W, ... (W = waves in the grid): `cursor`
+    // counts rays of that private sequence, sequence element v is trace slot
+    // ((v / 64) * W + w) * 64 + v % 64.  Dealing batches round-robin keeps waves balanced when
+    // rays are ordered by direction (neighbouring batches have similar traversal lengths).
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    uint32_t cursor = __builtin_amdgcn_readfirstlane(min((uint64_t)wave * p.chunk, (uint64_t)p.n));
-    const uint32_t chunk_end = __builtin_amdgcn_readfirstlane(min((uint64_t)(wave + 1) * p.chunk, (uint64_t)p.n));
+    const uint32_t W = gridDim.x * 4u;
+    uint32_t cursor = 0;
+    const uint32_t chunk_end = p.chunk;   // sequence length; slots >= n are skipped
+    const uint32_t n32 = (uint32_t)p.n;
 
     for (;;) {
         const bool idle = cur == REF_DONE;
@@ -459,8 +465,9 @@ __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
             if (idle) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                       __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                const uint32_t my = cursor + rank;
-                if (my < chunk_end) {
+                const uint32_t v = cursor + rank;
+                const uint32_t my = ((v >> 6) * W + wave) * 64u + (v & 63u);
+                if (v < chunk_end && my < n32) {
                     const float4 rec = p.rays[my];
                     r.dx = rec.x; r.dy = rec.y; r.dz = rec.z; r.oy = rec.w;
                     r.rx = p.recip[my];
@@ -497,6 +504,173 @@ __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
                 p.hits[li] = make_uint2(__float_as_uint(r.dist), r.triID);
             }
             if (r.dist != 1e30f) atomicAdd(&my_counts[r.triID], 1);   // extend.cl:94-98
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// extend v3: as k_extend_persist, but node-pair records are STAGED THROUGH LDS per wavefront.
+//
+// PMC evidence (profiles/r01_v3_extend_pmc_summary.txt): with one lane fetching its own 64-byte
+// record as four dwordx4 loads, the vector L1 takes 243 M accesses per launch (4 per record) and
+// is ~72 % busy; waves sit in s_waitcnt 58 % of the time.  Here the four lanes of a quad fetch
+// ONE record per load instruction (the quad reads its 64 contiguous bytes: one L1 access), four
+// instructions cover the quad's four records, and the 4x4 transpose happens in LDS.  The loads
+// are LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.  L1 accesses per record:
+// 4 -> 1.
+//
+// LDS per wave: 4 regions x 1 KiB; instruction k fills region k lane-linearly (an LDS-DMA
+// destination is wave-uniform base + 16*lane), so the record of lane l = 4q + k lies in region k
+// at byte 64q.  The bank-conflict swizzle goes on the SOURCE address: lane j of the quad fetches
+// logical part j^k, i.e. logical part p of that record sits in 16-byte slot p^k.  Lanes 4q..4q+3
+// (k = 0..3, same 64-dword bank window, regions 1 KiB apart) then read four distinct slots in
+// each ds_read_b128 -- conflict-free.
+constexpr int STG_STACK = 8;   // LDS stack entries per lane in the staged kernel (8 KB / block)
+
+template <bool EXACT>
+__device__ __forceinline__ void staged_step(RayState& r, uint32_t& cur, int& sp, uint32_t* ovf,
+                                            const SceneDev& sc, uint32_t (*s_stack)[256],
+                                            const float4* my_rec, bool have_rec, uint32_t* error_flag)
+{
+    const int tid = threadIdx.x;
+    bool pop = false;
+    if (have_rec) {                                        // inner node, record staged in LDS
+        const int k = tid & 3;
+        const float4 a = my_rec[0 ^ k], b = my_rec[1 ^ k], c = my_rec[2 ^ k], d = my_rec[3 ^ k];
+        float dist1 = intersect_aabb2<EXACT>(r, a.x, a.y, a.z, b.x, b.y, b.z);
+        float dist2 = intersect_aabb2<EXACT>(r, c.x, c.y, c.z, d.x, d.y, d.z);
+        uint32_t ref1 = __float_as_uint(a.w), ref2 = __float_as_uint(b.w);
+        if (dist1 > dist2) {
+            const float td = dist1; dist1 = dist2; dist2 = td;
+            const uint32_t tr = ref1; ref1 = ref2; ref2 = tr;
+        }
+        if (dist1 == 1e30f) pop = true;
+        else {
+            cur = ref1;
+            if (dist2 != 1e30f) {
+                if (sp < STG_STACK) s_stack[sp][tid] = ref2;
+                else if (sp < MAX_STACK) ovf[sp - STG_STACK] = ref2;
+                else *error_flag = 1u;
+                if (sp < MAX_STACK) ++sp;
+            }
+        }
+    } else if (cur != REF_DONE) {                          // leaf (cur has bit 31 set)
+        const uint32_t first = cur & REF_FIRST_MASK;
+        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
+        if (count == 15u) count = sc.leaf_count[first];
+        for (uint32_t i = 0; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
+        pop = true;
+    }
+    if (pop) {
+        if (sp == 0) cur = REF_DONE;
+        else {
+            --sp;
+            if (sp < STG_STACK) { cur = s_stack[sp][tid]; asm volatile("" : "+v"(cur)); }
+            else cur = ovf[sp - STG_STACK];
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_void_t;
+
+template <int REFILL_MIN>
+__global__ __launch_bounds__(256, 6) void k_extend_staged(ExtendParams p)
+{
+    __shared__ uint32_t s_stack[STG_STACK][256];
+    __shared__ float4 s_stage[4][4][64];                   // [wave][region k][lane]
+    uint32_t* const ovf = p.ovf_stack + ((size_t)blockIdx.x * 256 + threadIdx.x) * (MAX_STACK - STG_STACK);
+    RayState r;
+    r.ox = p.ox; r.oz = p.oz;
+    r.oy = 0.f; r.dx = r.dy = r.dz = 1.f; r.rx = r.ry = r.rz = 1.0; r.dist = 1e30f; r.triID = 0;
+    uint32_t cur = REF_DONE;
+    uint32_t slot = 0;
+    int sp = 0;
+    bool live = false, special = false;
+    int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
+
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 3;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 (*const stage)[64] = s_stage[wv];
+    // my own record: region (lane & 3), 64-byte block (lane >> 2)
+    const float4* const my_rec = &stage[lane & 3][(lane >> 2) * 4];
+    const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv;
+    const uint32_t W = gridDim.x * 4u;
+    uint32_t cursor = 0;
+    const uint32_t chunk_end = p.chunk;
+    const uint32_t n32 = (uint32_t)p.n;
+    const char* const pairs_bytes = (const char*)p.scene.pairs;
+
+    for (;;) {
+        const bool idle = cur == REF_DONE;
+        const unsigned long long idle_mask = __ballot(idle);
+        const int nidle = __popcll(idle_mask);
+        if (cursor < chunk_end && nidle >= REFILL_MIN) {
+            if (idle) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const uint32_t v = cursor + rank;
+                const uint32_t my = ((v >> 6) * W + wave) * 64u + (v & 63u);
+                if (v < chunk_end && my < n32) {
+                    const float4 rec = p.rays[my];
+                    r.dx = rec.x; r.dy = rec.y; r.dz = rec.z; r.oy = rec.w;
+                    r.rx = p.recip[my];
+                    r.ry = p.recip[p.recip_stride + my];
+                    r.rz = p.recip[2 * p.recip_stride + my];
+                    r.dist = 1e30f;
+                    r.triID = 0;
+                    slot = my;
+                    sp = 0;
+                    cur = p.scene.root_ref;
+                    live = true;
+                    const float ay = fabsf(r.oy);
+                    special = r.dx == 0.0f || r.dy == 0.0f || r.dz == 0.0f ||
+                              !(fabsf(r.dx) <= 1.0f) || !(fabsf(r.dy) <= 1.0f) || !(fabsf(r.dz) <= 1.0f) ||
+                              (ay != 0.0f && ay < 7.888609e-31f) || p.force_exact != 0;
+                }
+            }
+            cursor += (uint32_t)nidle;
+        }
+        const bool active = cur != REF_DONE;
+        if (!__any(active)) {
+            if (cursor >= chunk_end) break;
+            continue;
+        }
+        // ---- cooperative fetch: quad q loads the records of its own four lanes ----
+        const bool inner = cur < REF_LEAF_BIT;
+        if (__any(inner)) {
+            // record index of quad lane k, broadcast within the quad (DPP quad_perm, no LDS)
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)cur, 0x00, 0xf, 0xf, true);
+            const uint32_t c1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)cur, 0x55, 0xf, 0xf, true);
+            const uint32_t c2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)cur, 0xaa, 0xf, 0xf, true);
+            const uint32_t c3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)cur, 0xff, 0xf, 0xf, true);
+            if (c0 < REF_LEAF_BIT)
+                __builtin_amdgcn_global_load_lds((global_void_t*)(pairs_bytes + (size_t)c0 * 64 + ((j ^ 0) * 16)),
+                                                 (lds_void_t*)&stage[0][0], 16, 0, 0);
+            if (c1 < REF_LEAF_BIT)
+                __builtin_amdgcn_global_load_lds((global_void_t*)(pairs_bytes + (size_t)c1 * 64 + ((j ^ 1) * 16)),
+                                                 (lds_void_t*)&stage[1][0], 16, 0, 0);
+            if (c2 < REF_LEAF_BIT)
+                __builtin_amdgcn_global_load_lds((global_void_t*)(pairs_bytes + (size_t)c2 * 64 + ((j ^ 2) * 16)),
+                                                 (lds_void_t*)&stage[2][0], 16, 0, 0);
+            if (c3 < REF_LEAF_BIT)
+                __builtin_amdgcn_global_load_lds((global_void_t*)(pairs_bytes + (size_t)c3 * 64 + ((j ^ 3) * 16)),
+                                                 (lds_void_t*)&stage[3][0], 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA landed; same-wave reads follow
+        }
+        if (__any(active & special))
+            staged_step<true>(r, cur, sp, ovf, p.scene, s_stack, my_rec, inner, p.error_flag);
+        else
+            staged_step<false>(r, cur, sp, ovf, p.scene, s_stack, my_rec, inner, p.error_flag);
+
+        if (live && cur == REF_DONE) {
+            live = false;
+            if (p.hits) {
+                const uint32_t li = p.order ? p.order[slot] : slot;
+                p.hits[li] = make_uint2(__float_as_uint(r.dist), r.triID);
+            }
+            if (r.dist != 1e30f) atomicAdd(&my_counts[r.triID], 1);
         }
     }
 }
@@ -682,14 +856,14 @@ void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bi
 // variant = threshold code + 10 * grid code.  Threshold code: 0 default, 1 = v1 kernel (one ray
 // per lane, IEEE divisions, no refill), 2/3/4/5/6 = refill when >= 1/8/16/32/64 lanes are idle.
 // Grid code: workgroups per CU = 8 (0), 4 (1), 6 (2), 2 (3), 16 (4).
-void launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
+bool launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
 {
-    if (p0.n <= 0) return;
+    if (p0.n <= 0) return true;
     ExtendParams p = p0;
     const int tcode = variant % 10, gcode = (variant / 10) % 10;
     if (tcode == 1) {
         hipLaunchKernelGGL(k_extend, dim3(blocks_for(p.n, 256)), dim3(256), 0, s, p);
-        return;
+        return true;
     }
     static const unsigned per_cu[5] = {8, 4, 6, 2, 16};
     unsigned grid = 256u * per_cu[gcode < 5 ? gcode : 0];
@@ -697,6 +871,19 @@ void launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
     if (need < grid) grid = need;
     const uint64_t waves = (uint64_t)grid * 4;
     p.chunk = (uint32_t)((((uint64_t)p.n + waves - 1) / waves + 63) / 64 * 64);   // whole batches of 64
+    if (tcode >= 7) {   // staged kernels: 6 workgroups per CU unless a grid code says otherwise
+        if (gcode == 0) { grid = 256u * 6u; if (need < grid) grid = need; }
+        if ((uint64_t)grid * 256 * (MAX_STACK - STG_STACK) > p.ovf_capacity) return false;
+        const uint64_t w2 = (uint64_t)grid * 4;
+        p.chunk = (uint32_t)((((uint64_t)p.n + w2 - 1) / w2 + 63) / 64 * 64);
+        switch (tcode) {
+            case 8: hipLaunchKernelGGL(k_extend_staged<8>, dim3(grid), dim3(256), 0, s, p); break;
+            case 9: hipLaunchKernelGGL(k_extend_staged<32>, dim3(grid), dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL(k_extend_staged<16>, dim3(grid), dim3(256), 0, s, p); break;
+        }
+        return true;
+    }
+    if ((uint64_t)grid * 256 * (MAX_STACK - LDS_STACK) > p.ovf_capacity) return false;
     switch (tcode) {
         case 2: hipLaunchKernelGGL(k_extend_persist<1>, dim3(grid), dim3(256), 0, s, p); break;
         case 3: hipLaunchKernelGGL(k_extend_persist<8>, dim3(grid), dim3(256), 0, s, p); break;
@@ -704,6 +891,7 @@ void launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
         case 6: hipLaunchKernelGGL(k_extend_persist<64>, dim3(grid), dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL(k_extend_persist<16>, dim3(grid), dim3(256), 0, s, p); break;
     }
+    return true;
 }
 
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,

@@ -73,6 +73,33 @@ def test_extend_hits_and_counts_bit_exact(ctx, orc, oscene, oroute, sort_bits):
     ctx.set_record_hits(False)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 6, 7, 8, 9, 12, 27])
+def test_every_extend_variant_is_bit_exact(ctx, orc, oscene, oroute, variant):
+    """All kernel variants (v1 per-ray, persistent with different refill thresholds / grid sizes,
+    LDS-staged cooperative fetch) give the same bits: layout and scheduling never change results."""
+    n = 300000
+    lp = lamp_pos(orc, oscene, oroute, 5)
+    ctx.set_variant(variant)
+    ctx.set_sort_bits(0)
+    ctx.set_record_hits(True)
+    ctx.resize_rays(n)
+    ctx.reset(False)
+    ctx.seed = 7
+    ctx.generate(lp, oroute["lightLength"], 0, n)
+    ctx.extend(n)
+    ctx.sync()
+    got = ctx.read_rays(0, n)
+    counts = ctx.read_counts()
+    rays, _ = orc.generate(0, n, lp, oroute["lightLength"], 7)
+    temp = np.zeros(oscene.T, dtype=np.int32)
+    orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+    assert np.array_equal(bits(got["dist"]), bits(rays["dist"]))
+    assert np.array_equal(got["triID"], rays["triID"])
+    assert np.array_equal(counts, temp)
+    ctx.set_variant(0)
+    ctx.set_record_hits(False)
+
+
 def test_full_iteration_two_lamps_matches_survey_golden(ctx, orc, oscene, oroute):
     """generate -> extend -> accumulate per lamp, then computeDosage: SURVEY.md 8c golden run
     (N = 65 536, lamps 0 and 1) and the oracle, bit for bit."""
