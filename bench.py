@@ -81,7 +81,23 @@ def cpu_baseline(glb, route_xml, waves, photons):
     dose = c.dose()
     total = time.time() - t0
     tot = {k: sum(x[k] for x in c.stats) for k in ("rays", "aabb_tests", "tri_tests", "hits", "node_visits")}
+    # The reference's own cl/extend.cl, compiled unmodified for gfx950 (oracle/_ref), timed on this
+    # GPU on the last wave's rays: the closest thing to "the reference OpenCL path in the same run"
+    # (no OpenCL CPU device exists in ROCm).
+    ref_gpu = None
+    try:
+        if photons % 256 == 0 and orc.refgpu() is not None:
+            rr = rays.copy()
+            rr["dist"] = np.float32(1e30)
+            rr["triID"] = 0
+            _cnt, ms = orc.refgpu_extend(rr, s.tris, s.nodes, s.triIdx, reps=3)
+            ref_gpu = {"kernel": "cl/extend.cl render, -O2, correctly rounded divide, no fast-math",
+                       "ms_per_launch": round(ms, 3), "mray_s": round(photons / ms / 1e3, 1),
+                       "triID_equal_to_oracle": float((rr["triID"] == rays["triID"]).mean())}
+    except Exception as e:      # reporting only
+        ref_gpu = {"error": str(e)[:200]}
     return {
+        "reference_extend_cl_on_this_gpu": ref_gpu,
         "value": waves * photons / total / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
         "sample": "%d waves x %d photons, lamp 0 (the full step); generate is serial (defines the SEED "
                   "semantics), extend uses %d OpenMP threads; extend-only %.2f Mray/s"
