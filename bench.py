@@ -131,11 +131,17 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    rehearsal = world > ndev          # more ranks than GPUs: ranks share devices, collective over gloo
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import __graft_entry__ as g
     g.load_package()
@@ -145,7 +151,7 @@ def main():
     route_xml = os.path.join(ROOT, "tests", "golden", "lange_route.xml")
 
     # ---- product path: native loader + BVH + RayTracer on the HIP kernels -----------------
-    rt = host.RayTracer(glb, route_xml, device=local_rank)
+    rt = host.RayTracer(glb, route_xml, device=dev_index)
     rt.set_lamps(rt.lamps()[:1])              # lamp 0
     rt.photonCount = args.photons
     rt.maxIterations = args.waves * world
@@ -240,7 +246,7 @@ def main():
                                    % (rt.photonsPerLight, args.waves, " + RCCL SUM/MAX of the per-triangle maps"
                                       if world > 1 else ""),
                        "triangles": rt.mesh.triangleCount, "rays_per_step": rays_per_step,
-                       "parallelism": "launch-sharded x%d" % world},
+                       "parallelism": "launch-sharded x%d" % world + (" (REHEARSAL: ranks share a GPU, gloo)" if rehearsal else "")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -677,19 +677,26 @@ __global__ __launch_bounds__(256, 6) void k_extend_staged(ExtendParams p)
 
 // ----------------------------------------------------------- per-triangle kernels (O(T))
 
-// accumulate.cl:4-14; tempPhotonMap[i] is the (exact, integer) sum of the deposit replicas
+// accumulate.cl:4-14; tempPhotonMap[i] is the (exact, integer) sum of the deposit replicas.
+// Four lanes share a triangle: each sums (and clears) a quarter of the replicas, two DPP adds
+// combine them, lane 0 of the quad applies the reference's update.
 __global__ __launch_bounds__(256) void k_accumulate(double* __restrict__ photon_map,
                                                     double* __restrict__ max_map,
                                                     int32_t* __restrict__ counts, int32_t replicas,
                                                     int64_t stride, float time_step, int32_t T)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T) return;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int i = g >> 2, part = g & 3;
     int32_t total = 0;
-    for (int r = 0; r < replicas; ++r) {
-        total += counts[r * stride + i];
-        counts[r * stride + i] = 0;
+    if (i < T) {
+        for (int r = part; r < replicas; r += 4) {
+            total += counts[r * stride + i];
+            counts[r * stride + i] = 0;
+        }
     }
+    total += __builtin_amdgcn_mov_dpp(total, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    total += __builtin_amdgcn_mov_dpp(total, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    if (i >= T || part != 0) return;
     const double c = (double)total;
     photon_map[i] = photon_map[i] + c * (double)time_step;
     const double m = max_map[i];
@@ -898,7 +905,7 @@ void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int
                        int64_t stride, float time_step, int32_t T, hipStream_t s)
 {
     if (T <= 0) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(T, 256)), dim3(256), 0, s, photon_map,
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((int64_t)T * 4, 256)), dim3(256), 0, s, photon_map,
                        max_map, counts, replicas, stride, time_step, T);
 }
 

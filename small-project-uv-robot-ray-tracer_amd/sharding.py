@@ -10,7 +10,11 @@ by rank k % world, every rank advances generate.cl's SEED chain over all launche
     photonMap     f64[T]  SUM   (counts * duration: integers, exact in f64 -> order independent)
     maxPhotonMap  f64[T]  MAX   (exact)
 
-after which computeDosage gives every rank the single-GPU dose bit for bit.  Payload: 16 B per
+after which computeDosage gives every rank the single-GPU dose bit for bit.
+
+Load order: initialise torch's HIP runtime (torch.cuda.set_device / init) BEFORE the first uvrt
+context is created; a process that initialises /opt/rocm's libamdhip64 first leaves torch's
+bundled runtime without devices.  Payload: 16 B per
 triangle (0.7 MB for 45 k triangles) -- latency-bound, so the reduction happens once per
 computation, never once per launch.
 """

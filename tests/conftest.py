@@ -16,6 +16,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_first():
+    """On a GPU box initialise torch's HIP runtime BEFORE libuvrt_hip.so brings in its own
+    libamdhip64: a process that initialises HIP through /opt/rocm first leaves torch's bundled
+    runtime without devices ("No HIP GPUs are available").  bench.py has the same order."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def orc():
     import __graft_entry__ as g

@@ -118,3 +118,29 @@ def test_launch_sharding_union_equals_single(host, orc, oscene, oroute):
         rt.close()
     assert np.array_equal(maps[0][0] + maps[1][0], comp.photonMap)
     assert np.array_equal(np.maximum(maps[0][1], maps[1][1]), comp.maxPhotonMap)
+
+
+def test_device_maps_alias_as_torch_tensors(host, pkg):
+    """sharding.wrap_map: the context's f64 maps as zero-copy torch tensors (what the RCCL
+    reduction operates on)."""
+    torch = pytest.importorskip("torch")
+    from uvrt_amd import sharding
+    rt = host.RayTracer(GLB, ROUTE, device=0)
+    rt.set_lamps(rt.lamps()[:1])
+    rt.photonCount = 100000
+    rt.ResetDosageMap()
+    rt.ComputeDosageMap()
+    rt.Sync()
+    dev = torch.device("cuda", 0)
+    t_sum = sharding.wrap_map(rt.ctx, 0, dev)
+    t_max = sharding.wrap_map(rt.ctx, 1, dev)
+    assert t_sum.dtype == torch.float64 and t_sum.numel() == rt.mesh.triangleCount
+    assert np.array_equal(t_sum.cpu().numpy(), rt.ctx.read_photon_map(0))
+    assert np.array_equal(t_max.cpu().numpy(), rt.ctx.read_photon_map(1))
+    t_sum.mul_(2.0)                       # written through torch, seen by the context
+    torch.cuda.synchronize()
+    assert np.array_equal(rt.ctx.read_photon_map(0), t_sum.cpu().numpy())
+    red = sharding.MapReducer(rt.ctx, dev)
+    assert red.staged is False
+    red()                                 # world size 1: a no-op
+    rt.close()
