@@ -41,6 +41,8 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     if os.path.isdir("/root/reference/cl"):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    if os.path.exists(os.path.join(_HERE, "_ref", "ref_extend.co")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libref_gpu.so"])
 
 
 def lib():

@@ -79,7 +79,7 @@ struct uvrt_ctx {
     // rays
     int64_t capacity = 0;
     DevBuf rays, keyrank, sorted, order, hits, hist, bin_start, export_buf;
-    DevBuf recip, recip_sorted, ray_counter, ovf_stack;   // f64 reciprocals [3][capacity]; persistent-kernel cursor
+    DevBuf recip, recip_sorted, ovf_stack;   // f64 reciprocals [3][capacity]; persistent-kernel cursor
     bool scene_force_exact = false;            // a node bound too tiny for the reciprocal shortcut
     int32_t hist_bins = 0;
     int64_t last_n = -1;
@@ -173,7 +173,6 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
-    if (!rc) rc = c->ray_counter.ensure(sizeof(uint32_t), true, c->stream);
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
     if (!rc) rc = c->ovf_stack.ensure((size_t)OVF_MAX_ENTRIES * sizeof(uint32_t), false, c->stream);
     if (rc) { delete c; return rc; }
@@ -189,7 +188,7 @@ void uvrt_destroy(uvrt_ctx* c)
     for (DevBuf* b : {&c->pairs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
-                      &c->recip, &c->recip_sorted, &c->ray_counter, &c->ovf_stack, &c->error_flag})
+                      &c->recip, &c->recip_sorted, &c->ovf_stack, &c->error_flag})
         b->release();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

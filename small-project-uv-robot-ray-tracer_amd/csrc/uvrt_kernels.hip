@@ -386,9 +386,14 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
 {
     const int tid = threadIdx.x;
     bool pop = false;
+    // Speculative read of the stack top, issued next to the node-record loads: if this step ends
+    // in a pop the value is already in a register instead of costing an LDS round trip on the
+    // dependent path (a push in this step just leaves it unused).
+    uint32_t spec_top = REF_DONE;
     if (cur < REF_LEAF_BIT) {
         const PairRec* pr = sc.pairs + cur;
         const float4 a = pr->c0min_ref0, b = pr->c0max_ref1, c = pr->c1min, d = pr->c1max;
+        if (sp > 0 && sp <= LDS_STACK) spec_top = s_stack[sp - 1][tid];
         float dist1 = intersect_aabb2<EXACT>(r, a.x, a.y, a.z, b.x, b.y, b.z);
         float dist2 = intersect_aabb2<EXACT>(r, c.x, c.y, c.z, d.x, d.y, d.z);
         uint32_t ref1 = __float_as_uint(a.w), ref2 = __float_as_uint(b.w);
@@ -410,6 +415,7 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
         const uint32_t first = cur & REF_FIRST_MASK;
         uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
         if (count == 15u) count = sc.leaf_count[first];
+        if (sp > 0 && sp <= LDS_STACK) spec_top = s_stack[sp - 1][tid];
         for (uint32_t i = 0; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
         pop = true;
     }
@@ -417,12 +423,8 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
         if (sp == 0) cur = REF_DONE;
         else {
             --sp;
-            if (sp < LDS_STACK) {
-                cur = s_stack[sp][tid];
-                asm volatile("" : "+v"(cur));   // keeps this a ds_read (no flat load through a
-            } else {                            // pointer selected between LDS and scratch)
-                cur = ovf[sp - LDS_STACK];
-            }
+            if (sp < LDS_STACK) cur = spec_top;
+            else cur = ovf[sp - LDS_STACK];
         }
     }
 }

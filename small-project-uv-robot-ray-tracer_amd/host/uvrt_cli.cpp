@@ -5,8 +5,12 @@
 //
 //   uvrt_cli --room rooms/testroomopt.glb [--route-dir positions/] [--route lange_route]
 //            [--photons N] [--iterations K] [--lamps L] [--view dosage|maxpower]
-//            [--calibrate POWER HEIGHT DIST] [--device D] [--dump dose.f32] [--save-route name]
+//            [--calibrate POWER HEIGHT DIST] [--device D] [--save-route name]
+//            [--dump dose.f32 | dose.npy]   raw little-endian f32[T] or NumPy .npy (by extension)
+//            [--ply heatmap.ply]            the room with per-triangle heat-map colours
+//                                           (dosageToColor output; what the reference shows in GL)
 #include "raytracer.h"
+#include "../../include/uvrt.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +23,7 @@ using namespace Tmpl8;
 
 int main(int argc, char** argv)
 {
-    std::string room, routeDir = "positions/", route = "route", dump, saveRoute;
+    std::string room, routeDir = "positions/", route = "route", dump, saveRoute, ply;
     long long photons = -1;
     int iterations = -1, lamps = -1, device = 0;
     bool calibrate = false;
@@ -35,6 +39,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--lamps")) { need(1); lamps = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--device")) { need(1); device = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--dump")) { need(1); dump = argv[++i]; }
+        else if (!strcmp(argv[i], "--ply")) { need(1); ply = argv[++i]; }
         else if (!strcmp(argv[i], "--save-route")) { need(1); saveRoute = argv[++i]; }
         else if (!strcmp(argv[i], "--view")) { need(1); view = !strcmp(argv[++i], "maxpower") ? maxpower : dosage; }
         else if (!strcmp(argv[i], "--calibrate")) { need(3); calibrate = true; calP = (float)atof(argv[++i]); calH = (float)atof(argv[++i]); calD = (float)atof(argv[++i]); }
@@ -94,7 +99,43 @@ int main(int argc, char** argv)
            dose.size() > 3 ? dose[3] : 0.f);
     if (!dump.empty()) {
         std::ofstream f(dump, std::ios::binary);
+        if (dump.size() > 4 && dump.substr(dump.size() - 4) == ".npy") {
+            // NumPy format 1.0: magic, version, header length, dict padded to a 64-byte boundary
+            std::string hdr = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(dose.size()) + ",), }";
+            while ((10 + hdr.size() + 1) % 64) hdr += ' ';
+            hdr += '\n';
+            const unsigned short hl = (unsigned short)hdr.size();
+            f.write("\x93NUMPY\x01\x00", 8);
+            f.write((const char*)&hl, 2);
+            f.write(hdr.data(), (std::streamsize)hdr.size());
+        }
         f.write((const char*)dose.data(), (std::streamsize)dose.size() * 4);
+    }
+    if (!ply.empty()) {
+        std::vector<float> color((size_t)mesh.triangleCount * 9);
+        if (uvrt_read_color(rayTracer.ctx, color.data(), 0, mesh.triangleCount) != UVRT_OK) {
+            fprintf(stderr, "read_color: %s\n", uvrt_last_error());
+            return 1;
+        }
+        std::ofstream f(ply, std::ios::binary);
+        f << "ply\nformat binary_little_endian 1.0\ncomment UV dose heat map (dosageToColor)\n"
+          << "element vertex " << mesh.triangleCount * 3 << "\nproperty float x\nproperty float y\nproperty float z\n"
+          << "property uchar red\nproperty uchar green\nproperty uchar blue\n"
+          << "element face " << mesh.triangleCount << "\nproperty list uchar int vertex_indices\nend_header\n";
+        auto to8 = [](float v) { v = v < 0 ? 0 : (v > 1 ? 1 : v); return (unsigned char)(v * 255.0f + 0.5f); };
+        for (int i = 0; i < mesh.triangleCount; ++i)
+            for (int k = 0; k < 3; ++k) {
+                f.write((const char*)(mesh.vertices + (size_t)i * 9 + k * 3), 12);
+                const unsigned char rgb[3] = {to8(color[(size_t)i * 9 + k * 3]), to8(color[(size_t)i * 9 + k * 3 + 1]),
+                                              to8(color[(size_t)i * 9 + k * 3 + 2])};
+                f.write((const char*)rgb, 3);
+            }
+        for (int i = 0; i < mesh.triangleCount; ++i) {
+            const unsigned char three = 3;
+            const int idx[3] = {3 * i, 3 * i + 1, 3 * i + 2};
+            f.write((const char*)&three, 1);
+            f.write((const char*)idx, 12);
+        }
     }
     if (!saveRoute.empty()) {
         char name[32];
