@@ -4,9 +4,12 @@
 // result must equal the reference kernels' strict-IEEE arithmetic bit for bit, so each
 // operator below is one rounding in the order the reference source writes it.
 //
-//   k_generate        cl/generate.cl:8-40       + coherence key / rank for the ray ordering
-//   k_scan_bins, k_scatter                      counting sort of rays by coherence key
-//   k_extend          cl/extend.cl:6-99         BVH traversal + photon deposit (the hot loop)
+//   k_generate        cl/generate.cl:8-40       + f64 reciprocals, optional coherence key / rank
+//   k_scan_bins, k_scatter                      optional counting sort of rays by coherence key
+//   k_extend_persist  cl/extend.cl:6-99         BVH traversal + photon deposit -- THE hot loop
+//                                               (persistent waves, in-wave refill; default)
+//   k_extend_staged                             same, node records staged through LDS (A/B variant)
+//   k_extend                                    v1: one ray per lane, IEEE divisions (A/B variant)
 //   k_accumulate      cl/accumulate.cl:4-14
 //   k_reset           cl/reset.cl:4-26
 //   k_compute_dosage  cl/shade.cl:23-41

@@ -207,3 +207,36 @@ def test_no_scene_is_an_error(pkg):
             c.generate((0, 0, 0), 1.0, 0, 17)   # beyond capacity
     finally:
         c.close()
+
+
+def test_ray_range_sharding_equals_whole_launch(pkg, orc, oscene, oroute):
+    """BASELINE configs[3] ("pixel tile"): two contexts trace disjoint gid ranges of ONE launch
+    (global id in the seed, same SEED pair); their int counts add up to the unsharded launch."""
+    n = 500000
+    lp = lamp_pos(orc, oscene, oroute, 2)
+    whole = pkg.capi.Ctx(0)
+    whole.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+    whole.resize_rays(n)
+    whole.reset(False)
+    whole.seed = 99
+    whole.generate(lp, oroute["lightLength"], 0, n)
+    whole.extend(n)
+    whole.sync()
+    ref = whole.read_counts()
+    seed_after = whole.seed
+    total = np.zeros_like(ref)
+    cuts = [0, 123457, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c = pkg.capi.Ctx(0)
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        c.resize_rays(b - a)
+        c.reset(False)
+        c.seed = 99
+        c.generate(lp, oroute["lightLength"], a, b - a)
+        c.extend(b - a)
+        c.sync()
+        assert c.seed == seed_after          # every shard advances SEED identically
+        total += c.read_counts()
+        c.close()
+    whole.close()
+    assert np.array_equal(total, ref) and ref.sum() > 0.5 * n
