@@ -156,8 +156,13 @@ def main():
     rt.photonCount = args.photons
     rt.maxIterations = args.waves * world
     rt.set_shard(rank, world)
-    stream = torch.cuda.current_stream(device)
-    rt.ctx.set_stream(stream.cuda_stream)      # kernels and the collective share torch's stream
+    # One real (non-default) torch stream carries BOTH the uvrt kernels and the collective, so the
+    # reduction is ordered after the last accumulate and before the final Shade without host syncs.
+    # (torch's default stream has handle 0, which uvrt_set_stream reads as "use your own stream".)
+    stream = torch.cuda.Stream(device=device)
+    assert stream.cuda_stream != 0
+    rt.ctx.set_stream(stream.cuda_stream)
+    torch.cuda.set_stream(stream)
     if args.sort_bits is not None:
         rt.ctx.set_sort_bits(args.sort_bits)
     if args.variant is not None:
@@ -203,6 +208,16 @@ def main():
     rays_per_step = rt.maxIterations * rt.photonsPerLight
     value = rays_per_step * args.steps / elapsed / 1e6
     dose = rt.read_dosage()
+    ranks_agree = None
+    if world > 1:
+        # after the reduction every rank must hold the same maps, hence the same dose bits
+        import zlib
+        h = torch.tensor([zlib.crc32(dose.tobytes()), int(round(float(rt.ctx.read_photon_map(0).sum()) / 60.0))],
+                         dtype=torch.int64, device=device)
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        dist.all_gather(hs, h)
+        ranks_agree = all(bool((x == hs[0]).all()) for x in hs)
+        total_hits = int(hs[0][1].item())
 
     if rank == 0:
         # ---- CPU baseline + census (rank 0, N = 1 only) -----------------------------------
@@ -249,6 +264,9 @@ def main():
                        "parallelism": "launch-sharded x%d" % world + (" (REHEARSAL: ranks share a GPU, gloo)" if rehearsal else "")},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if world > 1:
+            out["multi_gpu_check"] = {"dose_identical_on_all_ranks": ranks_agree, "photons_deposited": total_hits,
+                                      "photons_traced": rays_per_step}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -78,7 +78,10 @@ def wrap_map(ctx, which, device):
 
 
 class MapReducer:
-    """Reduces a RayTracer's photonMap / maxPhotonMap across ranks on the context's stream.
+    """Reduces a RayTracer's photonMap / maxPhotonMap across ranks.  Ordering contract: the
+    context must run on torch's CURRENT stream (ctx.set_stream(torch.cuda.Stream().cuda_stream)
+    + torch.cuda.set_stream), which is the stream the collective is enqueued behind; with the
+    context on its own private stream call ctx.sync() before and torch.cuda.synchronize() after.
     Aliases the device arrays when torch accepts the array interface, otherwise stages through
     two torch buffers with uvrt_copy_device."""
 
