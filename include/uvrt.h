@@ -135,6 +135,8 @@ int uvrt_copy_device(uvrt_ctx* ctx, int32_t which, void* ext_dev_ptr, int32_t to
  * context's stream), and the number of extend launches; synchronises. */
 int uvrt_extend_time_ms(uvrt_ctx* ctx, double* ms, int64_t* launches);
 int uvrt_set_timing(uvrt_ctx* ctx, int32_t on);
+/* compute units of the context's device (the persistent extend grid is 8 workgroups per CU) */
+int uvrt_device_cus(uvrt_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("uvrt_copy_device", C.c_int, [_vp, _i32, _vp, _i32]),
     ("uvrt_extend_time_ms", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("uvrt_set_timing", C.c_int, [_vp, _i32]),
+    ("uvrt_device_cus", C.c_int, [_vp]),
 ]
 
 _LIB = None
@@ -215,6 +216,9 @@ class Ctx:
 
     def copy_device(self, which, ext_ptr, to_ctx):
         self._ck(self._L.uvrt_copy_device(self._h, int(which), C.c_void_p(int(ext_ptr)), int(bool(to_ctx))))
+
+    def device_cus(self):
+        return int(self._L.uvrt_device_cus(self._h))
 
     def device_ptr(self, which):
         p, b = C.c_void_p(), C.c_int64()

@@ -62,6 +62,7 @@ struct DevBuf {
 
 struct uvrt_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
@@ -151,6 +152,7 @@ extern "C" {
 
 const char* uvrt_last_error(void) { return g_err.c_str(); }
 const char* uvrt_version(void) { return "uvrt-mi355x 0.1 (gfx950)"; }
+int uvrt_device_cus(uvrt_ctx* c) { return c ? c->num_cus : 0; }
 
 int uvrt_create(int device_id, uvrt_ctx** out)
 {
@@ -169,6 +171,8 @@ int uvrt_create(int device_id, uvrt_ctx** out)
                     device_id, prop.gcnArchName);
     uvrt_ctx* c = new uvrt_ctx();
     c->device = device_id;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (c->num_cus > 256) c->num_cus = 256;   // the overflow-stack buffer is sized for 256 CUs x 16 workgroups
     HIP_TRY(hipSetDevice(device_id));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -457,6 +461,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
     p.ovf_stack = c->ovf_stack.as<uint32_t>();
     p.ovf_capacity = c->ovf_stack.bytes / sizeof(uint32_t);
+    p.num_cus = c->num_cus;
     p.counts = c->counts.as<int32_t>();
     p.count_replicas = c->replicas;
     p.count_stride = c->T;

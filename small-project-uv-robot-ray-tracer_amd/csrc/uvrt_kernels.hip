@@ -878,13 +878,14 @@ bool launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
         return true;
     }
     static const unsigned per_cu[5] = {8, 4, 6, 2, 16};
-    unsigned grid = 256u * per_cu[gcode < 5 ? gcode : 0];
+    const unsigned cus = p.num_cus > 0 ? (unsigned)p.num_cus : 256u;
+    unsigned grid = cus * per_cu[gcode < 5 ? gcode : 0];
     const unsigned need = blocks_for(p.n, 256);
     if (need < grid) grid = need;
     const uint64_t waves = (uint64_t)grid * 4;
     p.chunk = (uint32_t)((((uint64_t)p.n + waves - 1) / waves + 63) / 64 * 64);   // whole batches of 64
     if (tcode >= 7) {   // staged kernels: 6 workgroups per CU unless a grid code says otherwise
-        if (gcode == 0) { grid = 256u * 6u; if (need < grid) grid = need; }
+        if (gcode == 0) { grid = cus * 6u; if (need < grid) grid = need; }
         if ((uint64_t)grid * 256 * (MAX_STACK - STG_STACK) > p.ovf_capacity) return false;
         const uint64_t w2 = (uint64_t)grid * 4;
         p.chunk = (uint32_t)((((uint64_t)p.n + w2 - 1) / w2 + 63) / 64 * 64);
