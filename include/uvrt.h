@@ -120,6 +120,11 @@ int uvrt_set_variant(uvrt_ctx* ctx, int32_t variant);
 /* the rays of the last generate (+ extend, if hits were recorded) in the reference's 32-byte
  * Ray layout and gid order; synchronises. */
 int uvrt_read_rays(uvrt_ctx* ctx, void* rays32, int64_t first, int64_t count);
+/* test hook: replace the rays of the "last generate" by n host records in the reference's 32-byte
+ * Ray layout (dir, orig; dist/triID ignored).  All records must share orig.x and orig.z (rays of
+ * one lamp, generate.cl:16).  SEED is untouched.  Lets tests feed adversarial rays (zero
+ * direction components, origins on box planes) straight into uvrt_extend. */
+int uvrt_write_rays(uvrt_ctx* ctx, const void* rays32, int64_t n);
 int uvrt_read_counts(uvrt_ctx* ctx, int32_t* out, int32_t first, int32_t count);
 int uvrt_read_photon_map(uvrt_ctx* ctx, int32_t which_map, double* out, int32_t first,
                          int32_t count);

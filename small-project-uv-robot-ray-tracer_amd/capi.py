@@ -46,6 +46,7 @@ SYMBOLS = [
     ("uvrt_set_record_hits", C.c_int, [_vp, _i32]),
     ("uvrt_set_variant", C.c_int, [_vp, _i32]),
     ("uvrt_read_rays", C.c_int, [_vp, _vp, _i64, _i64]),
+    ("uvrt_write_rays", C.c_int, [_vp, _vp, _i64]),
     ("uvrt_read_counts", C.c_int, [_vp, _vp, _i32, _i32]),
     ("uvrt_read_photon_map", C.c_int, [_vp, _i32, _vp, _i32, _i32]),
     ("uvrt_device_ptr", C.c_int, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i64)]),
@@ -186,6 +187,10 @@ class Ctx:
         out = np.empty(count, dtype=RAY_DT)
         self._ck(self._L.uvrt_read_rays(self._h, _ptr(out), int(first), int(count)))
         return out
+
+    def write_rays(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        self._ck(self._L.uvrt_write_rays(self._h, _ptr(rays), rays.size))
 
     @property
     def seed(self):

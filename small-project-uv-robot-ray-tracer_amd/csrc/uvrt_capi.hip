@@ -633,6 +633,36 @@ int uvrt_read_rays(uvrt_ctx* c, void* rays32, int64_t first, int64_t count)
     return UVRT_OK;
 }
 
+int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
+{
+    if (!c || !rays32 || n <= 0 || n > c->capacity)
+        return fail(UVRT_ERR_INVALID, "uvrt_write_rays: n must be in (0, capacity]");
+    if (int rc = set_device(c)) return rc;
+    struct HostRay { float d[3], o[3], dist; uint32_t tri; };
+    const HostRay* hr = (const HostRay*)rays32;
+    std::vector<float> packed((size_t)n * 4);
+    std::vector<double> rec((size_t)n * 3);
+    for (int64_t i = 0; i < n; ++i) {
+        if (memcmp(&hr[i].o[0], &hr[0].o[0], 4) != 0 || memcmp(&hr[i].o[2], &hr[0].o[2], 4) != 0)
+            return fail(UVRT_ERR_INVALID, "uvrt_write_rays: record %lld has a different orig.x/orig.z", (long long)i);
+        packed[4 * i + 0] = hr[i].d[0]; packed[4 * i + 1] = hr[i].d[1];
+        packed[4 * i + 2] = hr[i].d[2]; packed[4 * i + 3] = hr[i].o[1];
+        for (int k = 0; k < 3; ++k) rec[(size_t)k * n + i] = 1.0 / (double)hr[i].d[k];   // as k_generate does
+    }
+    HIP_TRY(hipMemcpyAsync(c->rays.p, packed.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < 3; ++k)
+        HIP_TRY(hipMemcpyAsync((char*)c->recip.p + (size_t)k * c->capacity * 8, rec.data() + (size_t)k * n,
+                               (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_n = n;
+    c->last_first = 0;
+    c->last_sorted = false;
+    c->last_extended = false;
+    c->ox = hr[0].o[0];
+    c->oz = hr[0].o[2];
+    return UVRT_OK;
+}
+
 int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
 {
     if (!c || !ptr || !bytes || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: bad argument");
