@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--photons", type=int, default=PHOTONS)
     ap.add_argument("--waves", type=int, default=WAVES, help="waves (iterations) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): 8 waves per GPU, launches dealt to ranks, one SUM/MAX reduce per step; "
+                         "strong: BASELINE configs[3] -- the same 8 waves split by global-id range over the ranks "
+                         "('pixel tiles'), int32 count all-reduce per launch")
     ap.add_argument("--sort-bits", type=int, default=None)
     ap.add_argument("--variant", type=int, default=None)
     args = ap.parse_args()
@@ -154,8 +158,9 @@ def main():
     rt = host.RayTracer(glb, route_xml, device=dev_index)
     rt.set_lamps(rt.lamps()[:1])              # lamp 0
     rt.photonCount = args.photons
-    rt.maxIterations = args.waves * world
-    rt.set_shard(rank, world)
+    strong = args.scaling == "strong" and world > 1
+    rt.maxIterations = args.waves if strong else args.waves * world
+    rt.set_shard(0, 1) if strong else rt.set_shard(rank, world)
     # One real (non-default) torch stream carries BOTH the uvrt kernels and the collective, so the
     # reduction is ordered after the last accumulate and before the final Shade without host syncs.
     # (torch's default stream has handle 0, which uvrt_set_stream reads as "use your own stream".)
@@ -167,9 +172,34 @@ def main():
         rt.ctx.set_sort_bits(args.sort_bits)
     if args.variant is not None:
         rt.ctx.set_variant(args.variant)
-    reducer = sharding.MapReducer(rt.ctx, device) if world > 1 else None
+    reducer = sharding.MapReducer(rt.ctx, device) if (world > 1 and not strong) else None
 
-    def step():
+    if strong:
+        # ray-range sharding of every launch: rank r generates and traces global ids
+        # [r*n/world, (r+1)*n/world) (the global id feeds the seed, so the union is the unsharded
+        # launch), the int32 per-triangle counts are summed over ranks, then every rank accumulates.
+        n_launch = rt.photonsPerLight
+        share = (n_launch + world - 1) // world
+        first = min(rank * share, n_launch)
+        mine = min(share, n_launch - first)
+        lamp = rt.lamps()[0]
+        lp = (lamp[0], float(np.float32(np.float32(rt.mesh.floorHeight) + np.float32(rt.lightHeight))), lamp[1])
+        counts_t = sharding.wrap_array(rt.ctx, 2, device, "<i4")
+
+        def step():
+            rt.ctx.seed = 0
+            rt.ResetDosageMap()
+            for _ in range(args.waves):
+                rt.ctx.generate(lp, rt.lightLength, first, mine)
+                rt.ctx.extend(mine)
+                rt.ctx.device_ptr(2)                     # folds the deposit replicas into counts[0:T]
+                dist.all_reduce(counts_t, op=dist.ReduceOp.SUM)
+                rt.ctx.accumulate(lamp[2])
+                rt.photonMapSize = rt.photonMapSize + n_launch
+                rt.Shade()
+                rt.currIterations = rt.currIterations + 1
+
+    def _weak_step():
         rt.ctx.seed = 0                       # every step is the same computation (fresh-Init SEED)
         rt.ResetDosageMap()
         rt.set_shard(rank, world)             # restart the global launch index
@@ -180,6 +210,9 @@ def main():
         if reducer is not None:
             reducer()
             rt.Shade()
+
+    if not strong:
+        step = _weak_step
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -253,7 +286,7 @@ def main():
         out = {
             "metric": "Mray/s (extend+shade) on C046_1.glb 1920x1080x8-bounce", "value": round(value, 2),
             "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "testroomopt.glb (stand-in for the absent rooms/C046_1.glb), %d photons/launch "
                                    "x %d waves per GPU, lamp 0 of lange_route.xml, SEED_0=0; step = reset + waves x "
@@ -264,6 +297,8 @@ def main():
                        "parallelism": "launch-sharded x%d" % world + (" (REHEARSAL: ranks share a GPU, gloo)" if rehearsal else "")},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        import zlib
+        out["dose_crc32"] = "%08x" % zlib.crc32(dose.tobytes())
         if world > 1:
             out["multi_gpu_check"] = {"dose_identical_on_all_ranks": ranks_agree, "photons_deposited": total_hits,
                                       "photons_traced": rays_per_step}

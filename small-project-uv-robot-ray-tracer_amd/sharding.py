@@ -77,6 +77,18 @@ def wrap_map(ctx, which, device):
     return t
 
 
+def wrap_array(ctx, which, device, typestr):
+    """Any of the context's per-triangle arrays (uvrt_device_ptr numbering) as an aliasing torch
+    tensor; which = 2 is tempPhotonMap (int32, folded to its single-array form by the call)."""
+    import torch
+    ptr, nbytes = ctx.device_ptr(which)
+    itemsize = int(typestr[-1])
+    t = torch.as_tensor(_DevArray(ptr, (nbytes // itemsize,), typestr), device=device)
+    if t.data_ptr() != ptr:
+        raise capi.UvrtError("torch copied the device array instead of aliasing it")
+    return t
+
+
 class MapReducer:
     """Reduces a RayTracer's photonMap / maxPhotonMap across ranks.  Ordering contract: the
     context must run on torch's CURRENT stream (ctx.set_stream(torch.cuda.Stream().cuda_stream)
