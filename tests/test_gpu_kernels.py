@@ -240,3 +240,27 @@ def test_ray_range_sharding_equals_whole_launch(pkg, orc, oscene, oroute):
         c.close()
     whole.close()
     assert np.array_equal(total, ref) and ref.sum() > 0.5 * n
+
+
+def test_run_to_run_determinism(ctx, orc, oscene, oroute):
+    """Deposits are integer atomics and every other kernel is element-wise: two runs of the same
+    computation give identical counts, maps and dose bits whatever the scheduling."""
+    lp = lamp_pos(orc, oscene, oroute, 7)
+    n = 400000
+    out = []
+    ctx.set_variant(0)
+    ctx.set_sort_bits(0)
+    ctx.resize_rays(n)
+    for rep in range(3):
+        ctx.reset(True)
+        ctx.seed = 5
+        for _ in range(2):
+            ctx.generate(lp, oroute["lightLength"], 0, n)
+            ctx.extend(n)
+            ctx.accumulate(60.0)
+        ctx.compute_dosage(0, n, 44.0)
+        ctx.sync()
+        out.append((ctx.read_photon_map(0), ctx.read_photon_map(1), bits(ctx.read_dosage()), ctx.seed))
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+        assert np.array_equal(o[2], out[0][2]) and o[3] == out[0][3]
