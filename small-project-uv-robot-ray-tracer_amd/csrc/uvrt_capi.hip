@@ -70,6 +70,7 @@ struct uvrt_ctx {
     int32_t T = 0;
     DevBuf pairs, ltris, leaf_count, area;
     uint32_t root_ref = REF_DONE;
+    uint32_t top_pairs = 0;      // inner nodes of the first 7 tree levels (breadth-first prefix of `pairs`)
     bool have_scene = false;
     int32_t replicas = 1;        // deposit replicas of tempPhotonMap (uvrt_device.h ExtendParams)
     int32_t replicas_knob = -1;  // -1: choose from T
@@ -236,6 +237,8 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     std::vector<uint32_t> leaf_count(T, 0u);
     std::vector<PairRec> pairs;
     std::vector<int32_t> queue;   // inner nodes in BFS order; index in queue == pair index
+    std::vector<int32_t> depth;   // tree depth of queue[i]
+    uint32_t top_pairs = 0;
     int err = 0;
     bool tiny_bound = false;
     uint32_t root_ref;
@@ -244,6 +247,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     } else {
         root_ref = 0;
         queue.push_back(0);
+        depth.push_back(0);
     }
     for (size_t qi = 0; qi < queue.size() && !err; ++qi) {
         const HostNode& n = nodes[queue[qi]];
@@ -254,7 +258,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         for (int k = 0; k < 2; ++k) {
             const HostNode& ch = nodes[l + k];
             if (ch.triCount > 0) ref[k] = leaf_ref(ch, leaf_count, err);
-            else { ref[k] = (uint32_t)queue.size(); queue.push_back((int32_t)(l + k)); }
+            else { ref[k] = (uint32_t)queue.size(); queue.push_back((int32_t)(l + k)); depth.push_back(depth[qi] + 1); }
         }
         const HostNode& a = nodes[l];
         const HostNode& b = nodes[l + 1];
@@ -270,6 +274,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         pr.c1min = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.f);
         pr.c1max = make_float4(b.mx[0], b.mx[1], b.mx[2], 0.f);
         pairs.push_back(pr);
+        if (depth[qi] < 7 && top_pairs < 127) top_pairs = (uint32_t)qi + 1;   // level order: a prefix
     }
     if (err) return fail(UVRT_ERR_BVH, "uvrt_set_scene: malformed BVH (code %d)", err);
     if (pairs.size() >= (size_t)REF_LEAF_BIT) return fail(UVRT_ERR_BVH, "uvrt_set_scene: too many inner nodes");
@@ -278,7 +283,8 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     const bool resized = (T != c->T);
     int rc;
     if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
-    if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri), false, c->stream))) return rc;
+    // + 16 bytes: the merged record fetch of the traversal reads 64 bytes at every leaf record
+    if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri) + 16, true, c->stream))) return rc;
     if ((rc = c->leaf_count.ensure((size_t)T * 4, false, c->stream))) return rc;
     if ((rc = c->area.ensure((size_t)T * 4, false, c->stream))) return rc;
     if (resized || !c->photon_map.p) {
@@ -315,6 +321,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     if (e2 != hipSuccess) return fail(UVRT_ERR_HIP, "uvrt_set_scene: %s", hipGetErrorString(e2));
     c->T = T;
     c->root_ref = root_ref;
+    c->top_pairs = top_pairs;
     c->have_scene = true;
     c->scene_force_exact = tiny_bound;
     return UVRT_OK;
@@ -462,6 +469,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.ovf_stack = c->ovf_stack.as<uint32_t>();
     p.ovf_capacity = c->ovf_stack.bytes / sizeof(uint32_t);
     p.num_cus = c->num_cus;
+    p.top_pairs = c->top_pairs;
     p.counts = c->counts.as<int32_t>();
     p.count_replicas = c->replicas;
     p.count_stride = c->T;

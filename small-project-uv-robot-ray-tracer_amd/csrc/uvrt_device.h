@@ -67,6 +67,7 @@ struct ExtendParams {
     uint32_t* ovf_stack;     // persistent kernels: [grid threads][MAX_STACK - LDS entries] stack overflow
     uint64_t ovf_capacity;   // entries (uint32) available in ovf_stack; launches that need more are refused
     int32_t num_cus;         // compute units of the device (persistent grids are sized from it)
+    uint32_t top_pairs;      // pair records [0, top_pairs) = the tree levels cached in LDS (<= 127)
     int32_t force_exact;     // scene or lamp position outside the fast path's proof conditions
     const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)
     uint2* hits;             // [n] by local ray index: (dist bits, triID), or nullptr

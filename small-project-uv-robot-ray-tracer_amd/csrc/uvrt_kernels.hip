@@ -382,24 +382,83 @@ __device__ __forceinline__ void intersect_tri2(RayState& r, const LeafTri* __res
 
 // One traversal step of one lane (extend.cl:44-80): an inner node (test both children, order
 // them, descend / push / pop) or a leaf (test its triangles, pop).
-template <bool EXACT>
+// Top-of-tree cache: the first `top_pairs` node-pair records (breadth-first numbering: the upper
+// levels of the tree) are copied into LDS by every workgroup.  Part p of record r sits in 16-byte
+// slot (p + (r >> 2)) & 3 of its 64-byte block, which spreads the lanes of a ds_read_b128 over all
+// sixteen 4-bank windows instead of four.
+constexpr int TOP_MAX_PAIRS = 127;        // 7 complete levels; 8 KB of LDS with the padding record
+constexpr int PSTACK = 8;                 // LDS stack entries per lane in the persistent kernel
+
+__device__ __forceinline__ int top_slot(uint32_t r, int p) { return (int)((p + (r >> 2)) & 3u); }
+
+// Moeller-Trumbore on a leaf record already in registers (extend.cl:6-27)
+__device__ __forceinline__ void intersect_tri_regs(RayState& r, const float4 v0, const float4 e1, const float4 e2)
+{
+    const float hx = r.dy * e2.z - r.dz * e2.y;
+    const float hy = r.dz * e2.x - r.dx * e2.z;
+    const float hz = r.dx * e2.y - r.dy * e2.x;
+    const float a = e1.x * hx + e1.y * hy + e1.z * hz;
+    if (fabsf(a) < 0.00001f) return;
+    const float f = 1.0f / a;
+    const float sx = r.ox - v0.x, sy = r.oy - v0.y, sz = r.oz - v0.z;
+    const float u = f * (sx * hx + sy * hy + sz * hz);
+    if ((u < 0) | (u > 1)) return;
+    const float qx = sy * e1.z - sz * e1.y;
+    const float qy = sz * e1.x - sx * e1.z;
+    const float qz = sx * e1.y - sy * e1.x;
+    const float v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
+    if ((v < 0) | (u + v > 1)) return;
+    const float tt = f * (e2.x * qx + e2.y * qy + e2.z * qz);
+    if (tt > 0.0001f && tt < r.dist) {
+        r.dist = tt;
+        r.triID = __float_as_uint(v0.w);
+    }
+}
+
+// One traversal step of one lane (extend.cl:44-80).  The texture-data unit spends ~29 cycles on
+// every vector-load wave-instruction whatever its active lanes (profiles/: TD busy = 29 x VMEM
+// instructions, 85 % of the kernel), so inner-node lanes and leaf lanes share ONE set of four
+// load instructions per trip: the record address is a per-lane select between the pair array and
+// the leaf-triangle array, and the fourth 16 bytes are only used by inner lanes.
+template <bool EXACT, int NSTACK, bool TOP>
 __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& sp, uint32_t* ovf,
                                                const SceneDev& sc, uint32_t (*s_stack)[256],
+                                               const float4* s_top, uint32_t top_pairs,
                                                uint32_t* error_flag)
 {
     const int tid = threadIdx.x;
-    bool pop = false;
-    // Speculative read of the stack top, issued next to the node-record loads: if this step ends
-    // in a pop the value is already in a register instead of costing an LDS round trip on the
-    // dependent path (a push in this step just leaves it unused).
+    const bool is_inner = cur < REF_LEAF_BIT;
+    const bool is_leaf = !is_inner && cur != REF_DONE;
+    const uint32_t first = cur & REF_FIRST_MASK;
+    // byte offset of the record from the pair array's base; the leaf array is addressed relative
+    // to the same base so the select is one 64-bit value per lane
+    const char* base = (const char*)sc.pairs;
+    const int64_t off = is_inner ? (int64_t)cur * (int64_t)sizeof(PairRec)
+                                 : ((const char*)sc.ltris - base) + (int64_t)first * (int64_t)sizeof(LeafTri);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, w2 = w0, w3 = w0;
     uint32_t spec_top = REF_DONE;
-    if (cur < REF_LEAF_BIT) {
-        const PairRec* pr = sc.pairs + cur;
-        const float4 a = pr->c0min_ref0, b = pr->c0max_ref1, c = pr->c1min, d = pr->c1max;
-        if (sp > 0 && sp <= LDS_STACK) spec_top = s_stack[sp - 1][tid];
-        float dist1 = intersect_aabb2<EXACT>(r, a.x, a.y, a.z, b.x, b.y, b.z);
-        float dist2 = intersect_aabb2<EXACT>(r, c.x, c.y, c.z, d.x, d.y, d.z);
-        uint32_t ref1 = __float_as_uint(a.w), ref2 = __float_as_uint(b.w);
+    if (is_inner | is_leaf) {
+        if (sp > 0 && sp <= NSTACK) spec_top = s_stack[sp - 1][tid];
+        // exactly four 16-byte loads for inner and leaf lanes alike (hipcc would re-split them
+        // into six odd-sized ones); leaf lanes over-read 16 bytes, the leaf array is padded for it
+        const char* recp = base + off;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                     "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:48\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                     : "v"(recp)
+                     : "memory");
+    }
+    const float4 q0 = make_float4(w0.x, w0.y, w0.z, w0.w), q1 = make_float4(w1.x, w1.y, w1.z, w1.w),
+                 q2 = make_float4(w2.x, w2.y, w2.z, w2.w), q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
+    bool pop = false;
+    if (is_inner) {
+        float dist1 = intersect_aabb2<EXACT>(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+        float dist2 = intersect_aabb2<EXACT>(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z);
+        uint32_t ref1 = __float_as_uint(q0.w), ref2 = __float_as_uint(q1.w);
         if (dist1 > dist2) {
             const float td = dist1; dist1 = dist2; dist2 = td;
             const uint32_t tr = ref1; ref1 = ref2; ref2 = tr;
@@ -408,26 +467,25 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
         else {
             cur = ref1;
             if (dist2 != 1e30f) {
-                if (sp < LDS_STACK) s_stack[sp][tid] = ref2;
-                else if (sp < MAX_STACK) ovf[sp - LDS_STACK] = ref2;
+                if (sp < NSTACK) s_stack[sp][tid] = ref2;
+                else if (sp < MAX_STACK) ovf[sp - NSTACK] = ref2;
                 else *error_flag = 1u;
                 if (sp < MAX_STACK) ++sp;
             }
         }
-    } else if (cur != REF_DONE) {
-        const uint32_t first = cur & REF_FIRST_MASK;
+    } else if (is_leaf) {
         uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
         if (count == 15u) count = sc.leaf_count[first];
-        if (sp > 0 && sp <= LDS_STACK) spec_top = s_stack[sp - 1][tid];
-        for (uint32_t i = 0; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
+        intersect_tri_regs(r, q0, q1, q2);
+        for (uint32_t i = 1; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
         pop = true;
     }
     if (pop) {
         if (sp == 0) cur = REF_DONE;
         else {
             --sp;
-            if (sp < LDS_STACK) cur = spec_top;
-            else cur = ovf[sp - LDS_STACK];
+            if (sp < NSTACK) cur = spec_top;
+            else cur = ovf[sp - NSTACK];
         }
     }
 }
@@ -437,12 +495,22 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
 // their own wave's sequence (a wave-uniform cursor: no atomics, no inter-wave traffic), REFILL_MIN
 // idle lanes at a time, so the 64 lanes stay busy although ray lengths differ by an order of
 // magnitude (mean 32 steps, max ~200).
-template <int REFILL_MIN>
+template <int REFILL_MIN, bool TOP>
 __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
 {
-    __shared__ uint32_t s_stack[LDS_STACK][256];
-    // stack entries 16..31 of this thread (never touched on sane trees) live in global memory
-    uint32_t* const ovf = p.ovf_stack + ((size_t)blockIdx.x * 256 + threadIdx.x) * (MAX_STACK - LDS_STACK);
+    __shared__ uint32_t s_stack[PSTACK][256];                       // 8 KB
+    __shared__ float4 s_top[TOP ? (TOP_MAX_PAIRS + 1) * 4 : 4];     // 8 KB
+    // stack entries 8..31 of this thread (0.02 % of pushes on the test room) live in global memory
+    uint32_t* const ovf = p.ovf_stack + ((size_t)blockIdx.x * 256 + threadIdx.x) * (MAX_STACK - PSTACK);
+    const uint32_t top_pairs = TOP ? p.top_pairs : 0u;
+    if (TOP) {
+        const float4* src = (const float4*)p.scene.pairs;
+        for (uint32_t i = threadIdx.x; i < top_pairs * 4u; i += 256u) {
+            const uint32_t rec = i >> 2;
+            s_top[rec * 4u + (uint32_t)top_slot(rec, (int)(i & 3u))] = src[i];
+        }
+        __syncthreads();
+    }
     RayState r;
     r.ox = p.ox; r.oz = p.oz;
     r.oy = 0.f; r.dx = r.dy = r.dz = 1.f; r.rx = r.ry = r.rz = 1.0; r.dist = 1e30f; r.triID = 0;
@@ -469,6 +537,17 @@ __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
         const int nidle = __popcll(idle_mask);
         if (cursor < chunk_end && nidle >= REFILL_MIN) {
             if (idle) {
+                // results of the rays these lanes finished since the last refill: ONE atomic
+                // instruction per refill instead of one per loop trip (vector-memory instructions
+                // are the scarce resource: ~29 TD cycles each whatever the active lanes)
+                if (live) {
+                    live = false;
+                    if (p.hits) {
+                        const uint32_t li = p.order ? p.order[slot] : slot;
+                        p.hits[li] = make_uint2(__float_as_uint(r.dist), r.triID);
+                    }
+                    if (r.dist != 1e30f) atomicAdd(&my_counts[r.triID], 1);   // extend.cl:94-98
+                }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                       __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
                 const uint32_t v = cursor + rank;
@@ -499,18 +578,18 @@ __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
             continue;
         }
         if (__any(active & special))
-            traversal_step<true>(r, cur, sp, ovf, p.scene, s_stack, p.error_flag);
+            traversal_step<true, PSTACK, TOP>(r, cur, sp, ovf, p.scene, s_stack, s_top, top_pairs, p.error_flag);
         else
-            traversal_step<false>(r, cur, sp, ovf, p.scene, s_stack, p.error_flag);
+            traversal_step<false, PSTACK, TOP>(r, cur, sp, ovf, p.scene, s_stack, s_top, top_pairs, p.error_flag);
 
-        if (live && cur == REF_DONE) {                     // ray finished this trip: deposit
-            live = false;
-            if (p.hits) {
-                const uint32_t li = p.order ? p.order[slot] : slot;
-                p.hits[li] = make_uint2(__float_as_uint(r.dist), r.triID);
-            }
-            if (r.dist != 1e30f) atomicAdd(&my_counts[r.triID], 1);   // extend.cl:94-98
+    }
+    // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
+    if (live) {
+        if (p.hits) {
+            const uint32_t li = p.order ? p.order[slot] : slot;
+            p.hits[li] = make_uint2(__float_as_uint(r.dist), r.triID);
         }
+        if (r.dist != 1e30f) atomicAdd(&my_counts[r.triID], 1);       // extend.cl:94-98
     }
 }
 
@@ -866,8 +945,9 @@ void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bi
                        bin_start, sorted, order, recip_sorted, recip_stride, n);
 }
 
-// variant = threshold code + 10 * grid code.  Threshold code: 0 default, 1 = v1 kernel (one ray
-// per lane, IEEE divisions, no refill), 2/3/4/5/6 = refill when >= 1/8/16/32/64 lanes are idle.
+// variant = threshold code + 10 * grid code.  Threshold code: 0 default (refill at 16 idle
+// lanes), 1 = v1 kernel (one ray per lane, IEEE divisions, no refill), 2/3/5/6 = refill when
+// >= 1/8/32/64 lanes are idle, 4 = default + the top-of-tree LDS cache (measured: no gain).
 // Grid code: workgroups per CU = 8 (0), 4 (1), 6 (2), 2 (3), 16 (4).
 bool launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
 {
@@ -897,13 +977,14 @@ bool launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
         }
         return true;
     }
-    if ((uint64_t)grid * 256 * (MAX_STACK - LDS_STACK) > p.ovf_capacity) return false;
+    if ((uint64_t)grid * 256 * (MAX_STACK - PSTACK) > p.ovf_capacity) return false;
     switch (tcode) {
-        case 2: hipLaunchKernelGGL(k_extend_persist<1>, dim3(grid), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL(k_extend_persist<8>, dim3(grid), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL(k_extend_persist<32>, dim3(grid), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL(k_extend_persist<64>, dim3(grid), dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(k_extend_persist<16>, dim3(grid), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((k_extend_persist<1, false>), dim3(grid), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((k_extend_persist<8, false>), dim3(grid), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((k_extend_persist<16, true>), dim3(grid), dim3(256), 0, s, p); break;   // + top-of-tree LDS cache
+        case 5: hipLaunchKernelGGL((k_extend_persist<32, false>), dim3(grid), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((k_extend_persist<64, false>), dim3(grid), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((k_extend_persist<16, false>), dim3(grid), dim3(256), 0, s, p); break;
     }
     return true;
 }
