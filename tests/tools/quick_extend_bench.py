@@ -24,21 +24,27 @@ if os.environ.get("CHECK", "1") == "1":
     ref = np.zeros(s.T, dtype=np.int32)
     st = orc.extend(ref, s.tris, rays, s.nodes, s.triIdx)
     print("oracle stats", st, "B/ray %.1f" % orc.algorithmic_bytes_per_ray(st), flush=True)
-for v in variants:
-    for sb in sorts:
-        c.set_variant(v); c.set_sort_bits(sb); c.set_timing(True)
-        c.reset(False); c.seed = 0
-        c.generate(lp, route["lightLength"], 0, n); c.extend(n); c.sync()
-        ok = "-"
-        if ref is not None:
-            ok = "OK" if np.array_equal(c.read_counts(), ref) else "MISMATCH"
-        c.extend_time_ms()
-        reps = 5
-        c.sync(); t0 = time.time()
-        for _ in range(reps):
-            c.seed = 0
-            c.generate(lp, route["lightLength"], 0, n); c.extend(n); c.accumulate(60.0)
-        c.sync(); wall = (time.time() - t0) / reps
-        ms, k = c.extend_time_ms()
-        print("variant %d sort_bits %3d: counts %s  extend %.3f ms  (%.1f Mray/s)  wave wall %.3f ms (%.1f Mray/s)"
-              % (v, sb, ok, ms / k, n / (ms / k) / 1e3, wall * 1e3, n / wall / 1e6), flush=True)
+rounds = int(os.environ.get("ROUNDS", "3"))
+best = {}
+checked = {}
+for rnd in range(rounds):          # interleave the configurations: clocks ramp up over the first runs
+    for v in variants:
+        for sb in sorts:
+            c.set_variant(v); c.set_sort_bits(sb); c.set_timing(True)
+            c.reset(False); c.seed = 0
+            c.generate(lp, route["lightLength"], 0, n); c.extend(n); c.sync()
+            if ref is not None and (v, sb) not in checked:
+                checked[(v, sb)] = "OK" if np.array_equal(c.read_counts(), ref) else "MISMATCH"
+            c.extend_time_ms()
+            reps = 5
+            c.sync(); t0 = time.time()
+            for _ in range(reps):
+                c.seed = 0
+                c.generate(lp, route["lightLength"], 0, n); c.extend(n); c.accumulate(60.0)
+            c.sync(); wall = (time.time() - t0) / reps
+            ms, k = c.extend_time_ms()
+            b = best.setdefault((v, sb), [1e9, 1e9])
+            b[0] = min(b[0], ms / k); b[1] = min(b[1], wall * 1e3)
+for (v, sb), (ms, wall) in best.items():
+    print("variant %d sort_bits %3d: counts %s  extend %.3f ms  (%.1f Mray/s)  wave wall %.3f ms (%.1f Mray/s)"
+          % (v, sb, checked.get((v, sb), "-"), ms, n / ms / 1e3, wall, n / wall / 1e3), flush=True)
