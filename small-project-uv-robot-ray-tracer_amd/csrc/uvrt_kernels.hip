@@ -436,7 +436,8 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
     const int64_t off = is_inner ? (int64_t)cur * (int64_t)sizeof(PairRec)
                                  : ((const char*)sc.ltris - base) + (int64_t)first * (int64_t)sizeof(LeafTri);
     typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, w2 = w0, w3 = w0;
+    v4f w0, w1, w2, w3;   // deliberately not initialised: written by the loads below, read only
+                          // by the lanes that executed them (zero-filling costs 16 VALU per trip)
     uint32_t spec_top = REF_DONE;
     if (is_inner | is_leaf) {
         if (sp > 0 && sp <= NSTACK) spec_top = s_stack[sp - 1][tid];
@@ -452,13 +453,11 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
                      : "v"(recp)
                      : "memory");
     }
-    const float4 q0 = make_float4(w0.x, w0.y, w0.z, w0.w), q1 = make_float4(w1.x, w1.y, w1.z, w1.w),
-                 q2 = make_float4(w2.x, w2.y, w2.z, w2.w), q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
     bool pop = false;
     if (is_inner) {
-        float dist1 = intersect_aabb2<EXACT>(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-        float dist2 = intersect_aabb2<EXACT>(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z);
-        uint32_t ref1 = __float_as_uint(q0.w), ref2 = __float_as_uint(q1.w);
+        float dist1 = intersect_aabb2<EXACT>(r, w0.x, w0.y, w0.z, w1.x, w1.y, w1.z);
+        float dist2 = intersect_aabb2<EXACT>(r, w2.x, w2.y, w2.z, w3.x, w3.y, w3.z);
+        uint32_t ref1 = __float_as_uint(w0.w), ref2 = __float_as_uint(w1.w);
         if (dist1 > dist2) {
             const float td = dist1; dist1 = dist2; dist2 = td;
             const uint32_t tr = ref1; ref1 = ref2; ref2 = tr;
@@ -476,7 +475,8 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
     } else if (is_leaf) {
         uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
         if (count == 15u) count = sc.leaf_count[first];
-        intersect_tri_regs(r, q0, q1, q2);
+        intersect_tri_regs(r, make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
+                           make_float4(w2.x, w2.y, w2.z, w2.w));
         for (uint32_t i = 1; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
         pop = true;
     }
