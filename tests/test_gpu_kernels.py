@@ -264,3 +264,71 @@ def test_run_to_run_determinism(ctx, orc, oscene, oroute):
     for o in out[1:]:
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
         assert np.array_equal(o[2], out[0][2]) and o[3] == out[0][3]
+
+
+def test_abi_robustness_sequences(pkg, orc, oscene, oroute):
+    """Call sequences a host can legally produce: empty launches, scene swaps to a different
+    triangle count and back (CalibratePower), ray-buffer resizes, knobs toggled between launches."""
+    c = pkg.capi.Ctx(0)
+    try:
+        assert c.device_cus() > 0
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        lp = lamp_pos(orc, oscene, oroute, 1)
+        c.resize_rays(0)
+        c.generate(lp, 1.0, 0, 0)          # empty launch: nothing traced, SEED still advances
+        c.extend(0)
+        c.accumulate(60.0)
+        c.sync()
+        _, s1 = orc.generate(0, 1, lp, 1.0, 0)
+        assert c.seed == s1 and not c.read_photon_map(0).any()
+
+        def run(n, seed):
+            c.resize_rays(n)
+            c.reset(True)
+            c.seed = seed
+            c.generate(lp, oroute["lightLength"], 0, n)
+            c.extend(n)
+            c.sync()
+            return c.read_counts()
+
+        def ref(n, seed, tris, nodes, idx):
+            rays, _ = orc.generate(0, n, lp, oroute["lightLength"], seed)
+            t = np.zeros(tris.shape[0], dtype=np.int32)
+            orc.extend(t, tris, rays, nodes, idx)
+            return t
+
+        a = run(70000, 3)
+        assert np.array_equal(a, ref(70000, 3, oscene.tris, oscene.nodes, oscene.triIdx))
+        # swap to a tiny scene (different T: maps are reallocated), trace, swap back
+        tris2 = np.zeros((2, 16), dtype=np.float32)
+        tris2[0, 0:3] = (1, -2, 2); tris2[0, 4:7] = (-1, -2, 2); tris2[0, 8:11] = (1, 1, 2)
+        tris2[1, 0:3] = (-1, 1, 2); tris2[1, 4:7] = (-1, -2, 2); tris2[1, 8:11] = (1, 1, 2)
+        nodes2 = np.zeros(1, dtype=orc.NODE_DT); nodes2[0]["triCount"] = 2
+        idx2 = np.array([0, 1], dtype=np.uint32)
+        c.set_scene(tris2, nodes2, idx2)
+        b = run(5000, 4)
+        assert b.shape == (2,) and np.array_equal(b, ref(5000, 4, tris2, nodes2, idx2))
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        # knobs between launches, larger buffer after a smaller one
+        c.set_sort_bits(10)
+        c.set_record_hits(True)
+        d = run(130000, 5)
+        assert np.array_equal(d, ref(130000, 5, oscene.tris, oscene.nodes, oscene.triIdx))
+        got = c.read_rays(100, 50)
+        rays, _ = orc.generate(0, 130000, lp, oroute["lightLength"], 5)
+        assert np.array_equal(bits(got["dirx"]), bits(rays["dirx"][100:150]))
+        c.set_sort_bits(0)
+        c.set_record_hits(False)
+        c.set_timing(True)
+        run(64, 6)
+        ms, k = c.extend_time_ms()
+        assert k == 1 and ms > 0
+        c.set_timing(False)
+        with pytest.raises(pkg.capi.UvrtError):
+            c.read_rays(0, 65)             # beyond the last launch
+        with pytest.raises(pkg.capi.UvrtError):
+            c.read_dosage(0, oscene.T + 1)
+        with pytest.raises(pkg.capi.UvrtError):
+            c.extend(63)                   # does not match the last generate
+    finally:
+        c.close()
