@@ -127,3 +127,40 @@ def test_big_leaf_scene(pkg, orc):
         nd["maxx"], nd["maxy"], nd["maxz"] = v.max(0)
         nd["leftFirst"], nd["triCount"] = lo, hi - lo
     run_both(pkg, orc, ot, nodes2, np.arange(T, dtype=np.uint32), rays)
+
+
+def test_degenerate_triangles_give_nan_dose_like_the_reference(pkg, orc, oscene):
+    """Zero-area triangles: computeDosage divides by area * photonsPerLight = 0 (shade.cl:36-39,
+    SURVEY App. B): with no photon on them that is 0/0 = NaN.  Same NaN positions as the oracle,
+    identical bits everywhere else; the degenerate triangles do not disturb the trace either."""
+    tris = oscene.tris[:3000].copy()
+    tris[10, 4:7] = tris[10, 0:3]; tris[10, 8:11] = tris[10, 0:3]              # a point
+    tris[11, 0:3] = (0.5, 0.25, 1.0); tris[11, 4:7] = (1.5, 0.25, 1.0); tris[11, 8:11] = (2.5, 0.25, 1.0)   # collinear
+    ot = tris.copy()
+    nodes, idx = orc.build_bvh(ot)
+    n = 65536
+    lp = (-0.255, -0.995, -3.31)
+    rays, _ = orc.generate(0, n, lp, 1.0, 0)
+    temp = np.zeros(3000, dtype=np.int32)
+    orc.extend(temp, ot, rays, nodes, idx)
+    pm, mm = np.zeros(3000), np.zeros(3000)
+    counts = temp.copy()
+    orc.accumulate(pm, mm, temp, 60.0)
+    ref = orc.compute_dosage(pm, ot, n, 44.0)
+    c = pkg.capi.Ctx(0)
+    c.set_scene(ot, nodes, idx)
+    c.resize_rays(n)
+    c.reset(True)
+    c.generate(lp, 1.0, 0, n)
+    c.extend(n)
+    c.sync()
+    assert np.array_equal(c.read_counts(), counts) and counts[10] == 0 and counts[11] == 0
+    c.accumulate(60.0)
+    c.compute_dosage(0, n, 44.0)
+    c.sync()
+    got = c.read_dosage()
+    c.close()
+    assert np.isnan(ref[10]) and np.isnan(ref[11])
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(bits(got[ok]), bits(ref[ok])) and counts.sum() > 0

@@ -179,3 +179,48 @@ def test_malformed_bvh_is_rejected(pkg, orc):
     with pytest.raises(pkg.capi.UvrtError):
         c.set_scene(tris, np.zeros(1, dtype=orc.NODE_DT), np.array([0, 9], dtype=np.uint32))
     c.close()
+
+
+def test_reference_maximum_photon_count(host, orc, oscene, oroute):
+    """maxPhotonCount = 2^26 (raytracer.h:30) in ONE launch: beyond the reference's own int overflow
+    of `32 * photonCount` (raytracer.cpp:137) and deep into the regime where the
+    float seed merges neighbouring work-items.  Counts and dose equal the oracle."""
+    rt = host.RayTracer(GLB, ROUTE, device=0)
+    rt.set_lamps(rt.lamps()[5:6])
+    rt.photonCount = 1 << 26
+    rt.ResetDosageMap()
+    rt.ComputeDosageMap()
+    rt.Shade()
+    rt.Sync()
+    comp = orc.Computation(oscene, oroute["lamps"][5:6], 1 << 26, oroute["lightHeight"], oroute["lightLength"],
+                           oroute["lightIntensity"])
+    comp.reset()
+    comp.iteration()
+    assert rt.photonsPerLight == comp.photonsPerLight == 1 << 26
+    assert np.array_equal(rt.ctx.read_photon_map(0), comp.photonMap)
+    assert np.array_equal(bits(rt.read_dosage()), bits(comp.dose()))
+    rt.close()
+
+
+def test_second_init_restarts_seed_and_state(host, orc, oscene, oroute):
+    """Model reload calls Init again (userinterface.cpp:239-240): generate.cl is rebuilt, so SEED
+    restarts at 0; the mirror creates a fresh context."""
+    import ctypes
+    rt = host.RayTracer(GLB, ROUTE, device=0)
+    rt.set_lamps(rt.lamps()[:1])
+    rt.photonCount = 50000
+    rt.ResetDosageMap()
+    rt.ComputeDosageMap()
+    rt.Sync()
+    first = rt.ctx.read_photon_map(0)
+    assert rt.ctx.seed != 0
+    rt._L.uvrt_host_rt_init(rt._h, rt.mesh._h)                      # RayTracer::Init(mesh) again
+    rt.ctx = host._BorrowedCtx(rt._L.uvrt_host_rt_ctx(rt._h), rt.mesh.triangleCount)
+    assert rt.ctx.seed == 0
+    rt.set_lamps(rt.lamps()[:1])
+    rt.photonCount = 50000
+    rt.ResetDosageMap()
+    rt.ComputeDosageMap()
+    rt.Sync()
+    assert np.array_equal(rt.ctx.read_photon_map(0), first)
+    rt.close()

@@ -157,3 +157,13 @@ def test_route_matches_oracle_reader(host, orc, tmp_path):
     rt2.AddLamp()
     assert rt2.lamps() == [(0.0, 0.0, 1.0)] and rt2.photonsPerLight == 1 << 25
     rt.close(); rt2.close()
+
+
+def test_empty_lamp_list_does_not_divide_by_zero(host):
+    """raytracer.cpp:63 divides by lightPositions.size(); the mirror yields 0 photons per light."""
+    rt = host.RayTracer(init=False)
+    rt.set_lamps([])
+    assert rt.photonsPerLight == 0
+    rt.AddLamp(); rt.AddLamp(); rt.AddLamp()
+    assert rt.photonsPerLight == ((1 << 25) // 3) & ~1
+    rt.close()
