@@ -113,6 +113,12 @@ int uvrt_set_sort_bits(uvrt_ctx* ctx, int32_t bits);
 /* record (dist, triID) per ray in gid order during extend (the reference updates rays in
  * place, extend.cl:90-92); off by default, needed by uvrt_read_rays. */
 int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
+/* arithmetic flavour of IntersectTri's cross()/dot(): 0 (default) = the canonical strict flavour
+ * of SURVEY.md 8c (unfused); 1 = "ocl-amd", the fused multiply-add forms that ROCm's OpenCL
+ * device library gives the reference's extend.cl on gfx950 -- results then equal that kernel's,
+ * run live on the same GPU, bit for bit.  Everything else (slab test, traversal, deposit) is
+ * common to both flavours. */
+int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
 /* extend kernel variant: 0 = default; see DESIGN.md */
 int uvrt_set_variant(uvrt_ctx* ctx, int32_t variant);
 

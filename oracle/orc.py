@@ -78,6 +78,8 @@ def lib():
                                           C.c_int32]
         L.orc_floor_height.restype = C.c_float
         L.orc_floor_height.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_set_flavour.restype = None
+        L.orc_set_flavour.argtypes = [C.c_int]
         L.orc_bvh_build.restype = C.c_int32
         L.orc_bvh_build.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = L
@@ -195,6 +197,11 @@ def generate(first, n, lp, lightLength, SEED):
     lib().orc_generate(_p(rays), int(first), int(n), _f3(lp), float(np.float32(lightLength)),
                        C.byref(s))
     return rays, int(s.value)
+
+
+def set_flavour(flavour):
+    """0 = canonical strict arithmetic (default), 1 = "ocl-amd" (uvrt_oracle.h)."""
+    lib().orc_set_flavour(int(flavour))
 
 
 def extend(temp, tris, rays, nodes, triIdx, nthreads=0):

@@ -108,9 +108,44 @@ void orc_generate(orc_ray* rays, int64_t first, int64_t n, const float lp[3],
 static inline float cl_minf(float x, float y) { return y < x ? y : x; }
 static inline float cl_maxf(float x, float y) { return x < y ? y : x; }
 
+static int g_flavour = 0;
+void orc_set_flavour(int flavour) { g_flavour = flavour; }
+
+/* "ocl-amd" flavour of extend.cl:6-27 (see uvrt_oracle.h): fmaf() is exact also without FMA
+ * hardware (glibc software fma) */
+static inline float dot3_fma(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+static inline void intersect_tri_ocl(orc_ray* ray, const orc_tri* tri, uint32_t triID)
+{
+    const float e1x = tri->v1x - tri->v0x, e1y = tri->v1y - tri->v0y, e1z = tri->v1z - tri->v0z;
+    const float e2x = tri->v2x - tri->v0x, e2y = tri->v2y - tri->v0y, e2z = tri->v2z - tri->v0z;
+    const float hx = fmaf(ray->diry, e2z, -(ray->dirz * e2y));
+    const float hy = fmaf(ray->dirz, e2x, -(ray->dirx * e2z));
+    const float hz = fmaf(ray->dirx, e2y, -(ray->diry * e2x));
+    const float a = dot3_fma(e1x, e1y, e1z, hx, hy, hz);
+    if (fabsf(a) < 0.00001f) return;
+    const float f = 1.0f / a;
+    const float sx = ray->origx - tri->v0x, sy = ray->origy - tri->v0y, sz = ray->origz - tri->v0z;
+    const float u = f * dot3_fma(sx, sy, sz, hx, hy, hz);
+    if ((u < 0) | (u > 1)) return;
+    const float qx = fmaf(sy, e1z, -(sz * e1y));
+    const float qy = fmaf(sz, e1x, -(sx * e1z));
+    const float qz = fmaf(sx, e1y, -(sy * e1x));
+    const float v = f * dot3_fma(ray->dirx, ray->diry, ray->dirz, qx, qy, qz);
+    if ((v < 0) | (u + v > 1)) return;
+    const float t = f * dot3_fma(e2x, e2y, e2z, qx, qy, qz);
+    if (t > 0.0001f && t < ray->dist) {
+        ray->dist = t;
+        ray->triID = triID;
+    }
+}
+
 /* cl/extend.cl:6-27 */
 static inline void intersect_tri(orc_ray* ray, const orc_tri* tri, uint32_t triID)
 {
+    if (g_flavour == 1) { intersect_tri_ocl(ray, tri, triID); return; }
     const float e1x = tri->v1x - tri->v0x, e1y = tri->v1y - tri->v0y, e1z = tri->v1z - tri->v0z;
     const float e2x = tri->v2x - tri->v0x, e2y = tri->v2y - tri->v0y, e2z = tri->v2z - tri->v0z;
     /* h = cross(dir, edge2) */

@@ -82,6 +82,14 @@ uint32_t orc_generate_one(orc_ray* out, int32_t tid, const float lightPos[3], fl
 void orc_generate(orc_ray* rays, int64_t first, int64_t n, const float lightPos[3],
                   float lightLength, uint32_t* SEED);
 
+/* Arithmetic flavour of IntersectTri's cross()/dot() (extend.cl:14-24):
+ *   0 (default, canonical -- SURVEY.md 8c): unfused, dot = x*x + y*y + z*z, cross = a*b - c*d
+ *   1 "ocl-amd": what the reference's extend.cl becomes when built with ROCm's OpenCL device
+ *     library for gfx950 (oracle/_ref): cross(a,b).x = fma(a.y, b.z, -(a.z*b.y)) (and cyclic),
+ *     dot(a,b) = fma(a.z, b.z, fma(a.y, b.y, a.x*b.x)); read off the disassembly of
+ *     oracle/_ref/ref_extend.co.  Used to compare bit for bit with those kernels on the GPU. */
+void orc_set_flavour(int flavour);
+
 /* cl/extend.cl:85-99 over n rays (OpenMP over rays; counts are order independent).
  * stats may be NULL. nthreads <= 0 -> OpenMP default. */
 void orc_extend(int32_t* tempPhotonMap, const orc_tri* tris, orc_ray* rays, int64_t n,

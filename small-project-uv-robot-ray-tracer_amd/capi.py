@@ -44,6 +44,7 @@ SYMBOLS = [
     ("uvrt_seed_next", _u32, [_fp, _f32, _u32]),
     ("uvrt_set_sort_bits", C.c_int, [_vp, _i32]),
     ("uvrt_set_record_hits", C.c_int, [_vp, _i32]),
+    ("uvrt_set_flavour", C.c_int, [_vp, _i32]),
     ("uvrt_set_variant", C.c_int, [_vp, _i32]),
     ("uvrt_read_rays", C.c_int, [_vp, _vp, _i64, _i64]),
     ("uvrt_write_rays", C.c_int, [_vp, _vp, _i64]),
@@ -207,6 +208,9 @@ class Ctx:
 
     def set_record_hits(self, on):
         self._ck(self._L.uvrt_set_record_hits(self._h, int(bool(on))))
+
+    def set_flavour(self, f):
+        self._ck(self._L.uvrt_set_flavour(self._h, int(f)))
 
     def set_variant(self, v):
         self._ck(self._L.uvrt_set_variant(self._h, int(v)))

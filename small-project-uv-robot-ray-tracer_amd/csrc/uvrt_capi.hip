@@ -97,6 +97,7 @@ struct uvrt_ctx {
     int32_t sort_bits = 0;   // ray ordering off by default: extend is VALU-bound
     bool record_hits = false;
     int32_t variant = 0;
+    int32_t flavour = 0;
 
     // traversal error flag + extend timing
     DevBuf error_flag;
@@ -469,6 +470,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.ovf_stack = c->ovf_stack.as<uint32_t>();
     p.ovf_capacity = c->ovf_stack.bytes / sizeof(uint32_t);
     p.num_cus = c->num_cus;
+    p.flavour = c->flavour;
     p.top_pairs = c->top_pairs;
     p.counts = c->counts.as<int32_t>();
     p.count_replicas = c->replicas;
@@ -491,6 +493,8 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
     if (c->variant >= 100) p.force_exact = 1;   // experiment: IEEE divisions everywhere
+    if (c->flavour != 0 && c->variant % 100 != 0)
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default kernel (variant 0) only");
     if (!launch_extend(p, c->variant % 100, c->stream))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
@@ -611,6 +615,12 @@ int uvrt_set_record_hits(uvrt_ctx* c, int32_t on)
 {
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
     c->record_hits = on != 0;
+    return UVRT_OK;
+}
+int uvrt_set_flavour(uvrt_ctx* c, int32_t flavour)
+{
+    if (!c || (flavour != 0 && flavour != 1)) return fail(UVRT_ERR_INVALID, "uvrt_set_flavour: flavour must be 0 or 1");
+    c->flavour = flavour;
     return UVRT_OK;
 }
 int uvrt_set_variant(uvrt_ctx* c, int32_t variant)

@@ -69,6 +69,7 @@ struct ExtendParams {
     int32_t num_cus;         // compute units of the device (persistent grids are sized from it)
     uint32_t top_pairs;      // pair records [0, top_pairs) = the tree levels cached in LDS (<= 127)
     int32_t force_exact;     // scene or lamp position outside the fast path's proof conditions
+    int32_t flavour;         // 0 strict (canonical), 1 "ocl-amd" fused cross/dot in the triangle test
     const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)
     uint2* hits;             // [n] by local ray index: (dist bits, triID), or nullptr
     int32_t* counts;         // tempPhotonMap, count_replicas copies count_stride ints apart: a

@@ -392,6 +392,35 @@ constexpr int PSTACK = 8;                 // LDS stack entries per lane in the p
 __device__ __forceinline__ int top_slot(uint32_t r, int p) { return (int)((p + (r >> 2)) & 3u); }
 
 // Moeller-Trumbore on a leaf record already in registers (extend.cl:6-27)
+// "ocl-amd" flavour of the triangle test (include/uvrt.h uvrt_set_flavour): cross and dot as the
+// fused forms of ROCm's OpenCL library, everything else as extend.cl writes it
+__device__ __forceinline__ float dot3_fma(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+}
+__device__ __forceinline__ void intersect_tri_ocl(RayState& r, const float4 v0, const float4 e1, const float4 e2)
+{
+    const float hx = __builtin_fmaf(r.dy, e2.z, -(r.dz * e2.y));
+    const float hy = __builtin_fmaf(r.dz, e2.x, -(r.dx * e2.z));
+    const float hz = __builtin_fmaf(r.dx, e2.y, -(r.dy * e2.x));
+    const float a = dot3_fma(e1.x, e1.y, e1.z, hx, hy, hz);
+    if (fabsf(a) < 0.00001f) return;
+    const float f = 1.0f / a;
+    const float sx = r.ox - v0.x, sy = r.oy - v0.y, sz = r.oz - v0.z;
+    const float u = f * dot3_fma(sx, sy, sz, hx, hy, hz);
+    if ((u < 0) | (u > 1)) return;
+    const float qx = __builtin_fmaf(sy, e1.z, -(sz * e1.y));
+    const float qy = __builtin_fmaf(sz, e1.x, -(sx * e1.z));
+    const float qz = __builtin_fmaf(sx, e1.y, -(sy * e1.x));
+    const float v = f * dot3_fma(r.dx, r.dy, r.dz, qx, qy, qz);
+    if ((v < 0) | (u + v > 1)) return;
+    const float tt = f * dot3_fma(e2.x, e2.y, e2.z, qx, qy, qz);
+    if (tt > 0.0001f && tt < r.dist) {
+        r.dist = tt;
+        r.triID = __float_as_uint(v0.w);
+    }
+}
+
 __device__ __forceinline__ void intersect_tri_regs(RayState& r, const float4 v0, const float4 e1, const float4 e2)
 {
     const float hx = r.dy * e2.z - r.dz * e2.y;
@@ -420,7 +449,7 @@ __device__ __forceinline__ void intersect_tri_regs(RayState& r, const float4 v0,
 // instructions, 85 % of the kernel), so inner-node lanes and leaf lanes share ONE set of four
 // load instructions per trip: the record address is a per-lane select between the pair array and
 // the leaf-triangle array, and the fourth 16 bytes are only used by inner lanes.
-template <bool EXACT, int NSTACK, bool TOP>
+template <bool EXACT, int NSTACK, bool TOP, bool OCL>
 __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& sp, uint32_t* ovf,
                                                const SceneDev& sc, uint32_t (*s_stack)[256],
                                                const float4* s_top, uint32_t top_pairs,
@@ -475,9 +504,18 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
     } else if (is_leaf) {
         uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
         if (count == 15u) count = sc.leaf_count[first];
-        intersect_tri_regs(r, make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
-                           make_float4(w2.x, w2.y, w2.z, w2.w));
-        for (uint32_t i = 1; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
+        const float4 t0 = make_float4(w0.x, w0.y, w0.z, w0.w), t1 = make_float4(w1.x, w1.y, w1.z, w1.w),
+                     t2 = make_float4(w2.x, w2.y, w2.z, w2.w);
+        if (!OCL) {
+            intersect_tri_regs(r, t0, t1, t2);
+            for (uint32_t i = 1; i < count; ++i) intersect_tri2(r, sc.ltris + first + i);
+        } else {
+            intersect_tri_ocl(r, t0, t1, t2);
+            for (uint32_t i = 1; i < count; ++i) {
+                const LeafTri* lt = sc.ltris + first + i;
+                intersect_tri_ocl(r, lt->v0_id, lt->e1, lt->e2);
+            }
+        }
         pop = true;
     }
     if (pop) {
@@ -495,7 +533,7 @@ __device__ __forceinline__ void traversal_step(RayState& r, uint32_t& cur, int& 
 // their own wave's sequence (a wave-uniform cursor: no atomics, no inter-wave traffic), REFILL_MIN
 // idle lanes at a time, so the 64 lanes stay busy although ray lengths differ by an order of
 // magnitude (mean 32 steps, max ~200).
-template <int REFILL_MIN, bool TOP>
+template <int REFILL_MIN, bool TOP, bool OCL = false>
 __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
 {
     __shared__ uint32_t s_stack[PSTACK][256];                       // 8 KB
@@ -578,9 +616,9 @@ __global__ __launch_bounds__(256, 8) void k_extend_persist(ExtendParams p)
             continue;
         }
         if (__any(active & special))
-            traversal_step<true, PSTACK, TOP>(r, cur, sp, ovf, p.scene, s_stack, s_top, top_pairs, p.error_flag);
+            traversal_step<true, PSTACK, TOP, OCL>(r, cur, sp, ovf, p.scene, s_stack, s_top, top_pairs, p.error_flag);
         else
-            traversal_step<false, PSTACK, TOP>(r, cur, sp, ovf, p.scene, s_stack, s_top, top_pairs, p.error_flag);
+            traversal_step<false, PSTACK, TOP, OCL>(r, cur, sp, ovf, p.scene, s_stack, s_top, top_pairs, p.error_flag);
 
     }
     // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
@@ -978,6 +1016,10 @@ bool launch_extend(const ExtendParams& p0, int variant, hipStream_t s)
         return true;
     }
     if ((uint64_t)grid * 256 * (MAX_STACK - PSTACK) > p.ovf_capacity) return false;
+    if (p.flavour != 0) {   // "ocl-amd" triangle arithmetic: its own instantiation of the default kernel
+        hipLaunchKernelGGL((k_extend_persist<16, false, true>), dim3(grid), dim3(256), 0, s, p);
+        return true;
+    }
     switch (tcode) {
         case 2: hipLaunchKernelGGL((k_extend_persist<1, false>), dim3(grid), dim3(256), 0, s, p); break;
         case 3: hipLaunchKernelGGL((k_extend_persist<8, false>), dim3(grid), dim3(256), 0, s, p); break;

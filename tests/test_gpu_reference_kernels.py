@@ -84,3 +84,44 @@ def test_reference_shade_kernels_agree(ref, pkg, orc, oscene, oroute):
     assert ulp.max() <= 64
     assert np.allclose(r_dose, o_dose, rtol=1e-5)
     assert np.allclose(r_col, o_col, atol=1e-4)
+
+
+def test_ocl_flavour_is_bit_identical_to_the_reference_kernel(ref, pkg, orc, oscene, oroute):
+    """uvrt_set_flavour(1) swaps in the fused cross()/dot() forms that ROCm's OpenCL library gives
+    extend.cl: the HIP path then equals the reference's OWN compiled kernel -- running live on
+    this GPU -- bit for bit (dist bits, triID, count vector), on two lamps."""
+    n = 4096 * 256
+    comp = orc.Computation(oscene, oroute["lamps"], 1 << 16, oroute["lightHeight"], oroute["lightLength"],
+                           oroute["lightIntensity"])
+    c = pkg.capi.Ctx(0)
+    c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+    c.resize_rays(n)
+    c.set_record_hits(True)
+    c.set_flavour(1)
+    try:
+        for li, seed in ((0, 0), (9, 0x1234567)):
+            lp = comp.lamp_world_pos(oroute["lamps"][li])
+            rays, _ = orc.generate(0, n, lp, oroute["lightLength"], seed)
+            ref_rays = rays.copy()
+            ref_counts, _ = orc.refgpu_extend(ref_rays, oscene.tris, oscene.nodes, oscene.triIdx)
+            c.reset(False)
+            c.seed = seed
+            c.generate(lp, oroute["lightLength"], 0, n)
+            c.extend(n)
+            c.sync()
+            got = c.read_rays(0, n)
+            counts = c.read_counts()
+            assert np.array_equal(got["triID"], ref_rays["triID"])
+            assert np.array_equal(bits(got["dist"]), bits(ref_rays["dist"]))
+            assert np.array_equal(counts, ref_counts) and counts.sum() > 0.5 * n
+            # and the CPU oracle in the same flavour agrees too
+            orc.set_flavour(1)
+            try:
+                o_rays = rays.copy()
+                o_counts = np.zeros(oscene.T, dtype=np.int32)
+                orc.extend(o_counts, oscene.tris, o_rays, oscene.nodes, oscene.triIdx)
+            finally:
+                orc.set_flavour(0)
+            assert np.array_equal(bits(o_rays["dist"]), bits(ref_rays["dist"])) and np.array_equal(o_counts, ref_counts)
+    finally:
+        c.close()
