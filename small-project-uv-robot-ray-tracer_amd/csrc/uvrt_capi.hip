@@ -68,7 +68,8 @@ struct uvrt_ctx {
 
     // scene
     int32_t T = 0;
-    DevBuf pairs, ltris, leaf_count, area;
+    DevBuf pairs, lpairs, ltris, leaf_count, area;
+    int32_t npairs = 0;
     uint32_t root_ref = REF_DONE;
     uint32_t top_pairs = 0;      // inner nodes of the first 7 tree levels (breadth-first prefix of `pairs`)
     bool have_scene = false;
@@ -82,7 +83,7 @@ struct uvrt_ctx {
     int64_t capacity = 0;
     DevBuf rays, keyrank, sorted, order, hits, hist, bin_start, export_buf;
     DevBuf recip, recip_sorted, ovf_stack;   // f64 reciprocals [3][capacity]; persistent-kernel cursor
-    bool scene_force_exact = false;            // a node bound too tiny for the reciprocal shortcut
+    bool scene_force_exact = false;            // a node bound too tiny / too large for the reciprocal shortcuts
     int32_t hist_bins = 0;
     int64_t last_n = -1;
     int64_t last_first = 0;
@@ -191,7 +192,7 @@ void uvrt_destroy(uvrt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->pairs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
+    for (DevBuf* b : {&c->pairs, &c->lpairs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
                       &c->recip, &c->recip_sorted, &c->ovf_stack, &c->error_flag})
@@ -266,7 +267,8 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         for (const HostNode* hn : {&a, &b})
             for (int k = 0; k < 3; ++k)
                 for (float v : {hn->mn[k], hn->mx[k]})
-                    if (v != 0.0f && std::fabs(v) < 8.6736174e-19f) tiny_bound = true;   // 2^-60
+                    if ((v != 0.0f && std::fabs(v) < 8.6736174e-19f) || !(std::fabs(v) <= 1e18f))
+                        tiny_bound = true;   // below 2^-60, above 2^59.8, inf or NaN
         PairRec pr;
         pr.c0min_ref0 = make_float4(a.mn[0], a.mn[1], a.mn[2], 0.f);
         pr.c0max_ref1 = make_float4(a.mx[0], a.mx[1], a.mx[2], 0.f);
@@ -284,6 +286,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     const bool resized = (T != c->T);
     int rc;
     if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
+    if ((rc = c->lpairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
     // + 16 bytes: the merged record fetch of the traversal reads 64 bytes at every leaf record
     if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri) + 16, true, c->stream))) return rc;
     if ((rc = c->leaf_count.ensure((size_t)T * 4, false, c->stream))) return rc;
@@ -323,6 +326,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->T = T;
     c->root_ref = root_ref;
     c->top_pairs = top_pairs;
+    c->npairs = (int32_t)pairs.size();
     c->have_scene = true;
     c->scene_force_exact = tiny_bound;
     return UVRT_OK;
@@ -463,7 +467,8 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         // conditions of the reciprocal shortcut that are uniform over the launch (slab<>())
         const float ax = std::fabs(c->ox), az = std::fabs(c->oz);
         const float tiny = 7.888609e-31f;   // 2^-100
-        p.force_exact = (c->scene_force_exact || (ax != 0.0f && ax < tiny) || (az != 0.0f && az < tiny)) ? 1 : 0;
+        p.force_exact = (c->scene_force_exact || (ax != 0.0f && ax < tiny) || (az != 0.0f && az < tiny) ||
+                         !(ax <= 1e18f) || !(az <= 1e18f)) ? 1 : 0;
     }
     p.order = c->last_sorted ? c->order.as<uint32_t>() : nullptr;
     p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
@@ -479,6 +484,8 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.ox = c->ox;
     p.oz = c->oz;
     p.n = n;
+    p.lpairs = c->lpairs.p;
+    p.npairs = c->npairs;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -492,10 +499,16 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         ++c->ev_used;
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    if (c->variant >= 100) p.force_exact = 1;   // experiment: IEEE divisions everywhere
-    if (c->flavour != 0 && c->variant % 100 != 0)
+    // variants: 0-99 see launch_extend; +100 = the same with IEEE divisions everywhere;
+    // 200-299 = extend v5 (leaf period code + 10 * grid code); 300-399 = v5 with IEEE divisions
+    const bool v5 = c->variant >= 200 && c->variant < 400;
+    if ((c->variant >= 100 && c->variant < 200) || c->variant >= 300) p.force_exact = 1;
+    if (c->flavour != 0 && c->variant != 0)
         return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default kernel (variant 0) only");
-    if (!launch_extend(p, c->variant % 100, c->stream))
+    static const int per_cu5[5] = {8, 4, 6, 2, 16};
+    const int g5 = (c->variant / 10) % 10;
+    if (v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], c->stream)
+           : !launch_extend(p, c->variant % 100, c->stream))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));

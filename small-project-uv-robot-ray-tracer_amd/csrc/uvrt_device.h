@@ -80,6 +80,8 @@ struct ExtendParams {
     uint32_t* error_flag;    // set to 1 on traversal stack overflow
     float ox, oz;            // launch-uniform origin components
     int64_t n;
+    void* lpairs;            // extend v5: per-launch node-pair records (uvrt_extend5.hip), npairs x 64 B
+    int32_t npairs;
 };
 
 // launch wrappers (uvrt_kernels.hip)
@@ -90,6 +92,8 @@ void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bi
                     int64_t n, hipStream_t s);
 // returns false (nothing launched) when the variant's grid would not fit the overflow-stack buffer
 bool launch_extend(const ExtendParams& p, int variant, hipStream_t s);
+// extend v5 (uvrt_extend5.hip): leaf_code 0..3 = leaf visits every 1/2/3/4 trips
+bool launch_extend5(const ExtendParams& p, int leaf_code, int grid_per_cu, hipStream_t s);
 constexpr uint64_t OVF_MAX_ENTRIES = (uint64_t)256 * 16 * 256 * 24;   // largest grid x deepest overflow
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,
                        int64_t stride, float time_step, int32_t T, hipStream_t s);
