@@ -68,7 +68,7 @@ struct uvrt_ctx {
 
     // scene
     int32_t T = 0;
-    DevBuf pairs, lpairs, ltris, leaf_count, area;
+    DevBuf pairs, lpairs, recs, ltris, leaf_count, area;
     int32_t npairs = 0;
     uint32_t root_ref = REF_DONE;
     uint32_t top_pairs = 0;      // inner nodes of the first 7 tree levels (breadth-first prefix of `pairs`)
@@ -192,7 +192,7 @@ void uvrt_destroy(uvrt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->pairs, &c->lpairs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
+    for (DevBuf* b : {&c->pairs, &c->lpairs, &c->recs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
                       &c->recip, &c->recip_sorted, &c->ovf_stack, &c->error_flag})
@@ -226,6 +226,14 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     for (int32_t i = 0; i < T; ++i)
         if (tri_idx[i] >= (uint32_t)T)
             return fail(UVRT_ERR_BVH, "uvrt_set_scene: triIdx[%d] = %u >= tri_count %d", i, tri_idx[i], T);
+    // vertex coordinates beyond 1e9 (or non-finite): the shortcuts' range proofs do not cover them
+    bool huge_vertex = false;
+    {
+        const float* tv = (const float*)tris64;
+        for (int64_t i = 0; i < (int64_t)T && !huge_vertex; ++i)
+            for (int k = 0; k < 12; ++k)
+                if ((k & 3) != 3 && !(std::fabs(tv[i * 16 + k]) <= 1e9f)) { huge_vertex = true; break; }
+    }
 
     // Re-layout: walk the tree breadth-first from node 0; every inner node becomes one pair
     // record (numbered in visit order, so the top of the tree is contiguous at the front).
@@ -267,8 +275,8 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         for (const HostNode* hn : {&a, &b})
             for (int k = 0; k < 3; ++k)
                 for (float v : {hn->mn[k], hn->mx[k]})
-                    if ((v != 0.0f && std::fabs(v) < 8.6736174e-19f) || !(std::fabs(v) <= 1e18f))
-                        tiny_bound = true;   // below 2^-60, above 2^59.8, inf or NaN
+                    if ((v != 0.0f && std::fabs(v) < 8.6736174e-19f) || !(std::fabs(v) <= 1e9f))
+                        tiny_bound = true;   // below 2^-60, above 1e9, inf or NaN
         PairRec pr;
         pr.c0min_ref0 = make_float4(a.mn[0], a.mn[1], a.mn[2], 0.f);
         pr.c0max_ref1 = make_float4(a.mx[0], a.mx[1], a.mx[2], 0.f);
@@ -287,6 +295,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     int rc;
     if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
     if ((rc = c->lpairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
+    if ((rc = c->recs.ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
     // + 16 bytes: the merged record fetch of the traversal reads 64 bytes at every leaf record
     if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri) + 16, true, c->stream))) return rc;
     if ((rc = c->leaf_count.ensure((size_t)T * 4, false, c->stream))) return rc;
@@ -316,6 +325,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     if (e1 == hipSuccess && e2 == hipSuccess) {
         launch_prepare_scene(d_tris.as<float4>(), d_idx.as<uint32_t>(), c->ltris.as<LeafTri>(),
                              c->area.as<float>(), T, c->stream);
+        launch_prepare_leaves6(c->ltris.as<LeafTri>(), c->recs.p, (int32_t)pairs.size(), T, c->stream);
         e1 = hipGetLastError();
         e2 = hipStreamSynchronize(c->stream);
     }
@@ -328,7 +338,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->top_pairs = top_pairs;
     c->npairs = (int32_t)pairs.size();
     c->have_scene = true;
-    c->scene_force_exact = tiny_bound;
+    c->scene_force_exact = tiny_bound || huge_vertex;
     return UVRT_OK;
 }
 
@@ -468,7 +478,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         const float ax = std::fabs(c->ox), az = std::fabs(c->oz);
         const float tiny = 7.888609e-31f;   // 2^-100
         p.force_exact = (c->scene_force_exact || (ax != 0.0f && ax < tiny) || (az != 0.0f && az < tiny) ||
-                         !(ax <= 1e18f) || !(az <= 1e18f)) ? 1 : 0;
+                         !(ax <= 1e9f) || !(az <= 1e9f)) ? 1 : 0;
     }
     p.order = c->last_sorted ? c->order.as<uint32_t>() : nullptr;
     p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
@@ -486,6 +496,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.n = n;
     p.lpairs = c->lpairs.p;
     p.npairs = c->npairs;
+    p.recs = c->recs.p;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -501,14 +512,21 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     }
     // variants: 0-99 see launch_extend; +100 = the same with IEEE divisions everywhere;
     // 200-299 = extend v5 (leaf period code + 10 * grid code); 300-399 = v5 with IEEE divisions
+    // 400-499 = extend v6 (code + 10 * grid code, uvrt_extend6.hip); 500-599 = v6 with IEEE divisions
     const bool v5 = c->variant >= 200 && c->variant < 400;
-    if ((c->variant >= 100 && c->variant < 200) || c->variant >= 300) p.force_exact = 1;
+    const bool v6 = c->variant >= 400 && c->variant < 600;
+    if ((c->variant >= 100 && c->variant < 200) || (c->variant >= 300 && c->variant < 400) || c->variant >= 500)
+        p.force_exact = 1;
     if (c->flavour != 0 && c->variant != 0)
         return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default kernel (variant 0) only");
     static const int per_cu5[5] = {8, 4, 6, 2, 16};
     const int g5 = (c->variant / 10) % 10;
-    if (v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], c->stream)
-           : !launch_extend(p, c->variant % 100, c->stream))
+    const bool v6_ok = (size_t)c->npairs + (size_t)c->T < (size_t)MAX_TRIS;   // record index fits the reference
+    if (v6 && !v6_ok)
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: scene too large for extend v6's record numbering");
+    if (v6 ? !launch_extend6(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], c->stream)
+        : v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], c->stream)
+             : !launch_extend(p, c->variant % 100, c->stream))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));

@@ -82,6 +82,8 @@ struct ExtendParams {
     int64_t n;
     void* lpairs;            // extend v5: per-launch node-pair records (uvrt_extend5.hip), npairs x 64 B
     int32_t npairs;
+    void* recs;              // extend v6: [npairs] per-launch pair records + [T] leaf records, 64 B each
+    uint32_t root_ref6;      // root reference in v6's record numbering (set by launch_extend6)
 };
 
 // launch wrappers (uvrt_kernels.hip)
@@ -94,6 +96,9 @@ void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bi
 bool launch_extend(const ExtendParams& p, int variant, hipStream_t s);
 // extend v5 (uvrt_extend5.hip): leaf_code 0..3 = leaf visits every 1/2/3/4 trips
 bool launch_extend5(const ExtendParams& p, int leaf_code, int grid_per_cu, hipStream_t s);
+// extend v6 (uvrt_extend6.hip), the default: code bits 0-1 = leaf period - 1, bit 2 = no LDS top cache
+bool launch_extend6(const ExtendParams& p, int code, int grid_per_cu, hipStream_t s);
+void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, int32_t T, hipStream_t s);
 constexpr uint64_t OVF_MAX_ENTRIES = (uint64_t)256 * 16 * 256 * 24;   // largest grid x deepest overflow
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,
                        int64_t stride, float time_step, int32_t T, hipStream_t s);

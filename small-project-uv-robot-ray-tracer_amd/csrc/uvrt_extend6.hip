@@ -1,0 +1,397 @@
+// uvrt_extend6.hip -- extend v6 (cl/extend.cl:6-99), the default traversal kernel.
+//
+// Same algorithm as k_extend_persist (uvrt_kernels.hip): persistent wavefronts over statically owned
+// 64-ray batches, in-wave refill, one traversal step per lane and loop trip, the reference's visit
+// order / tests / comparisons.  What differs is the instruction stream of a trip, which is what
+// bounds the kernel (VALU issue, then the L1's one-line-per-clock lookup rate):
+//
+//  * slab distances t = (b - o) / d as PACKED f32, two quotients per instruction:
+//        q0 = a * y;  r = fma(-d, q0, a);  q = fma(r, y, q0)      with y = RN32(1/d)
+//    equals RN32(a / d) for all normal operands -- proven by exhaustion over all 2^46 significand
+//    pairs on the GPU (tests/tools/div3_exhaustive.hip, profiles/r01_div3_exhaustive.log);
+//  * f = 1 / a of the triangle test (extend.cl:17) as v_rcp_f32 + one Newton step, which is the
+//    correctly rounded reciprocal for every binary32 in [2^-64, 2^64) (tests/tools/rcp_exhaustive.hip);
+//  * the x / z numerators a = b - o use the lamp's launch-uniform coordinates: k_prepare_launch6
+//    writes per-launch node-pair records with that subtraction applied, (min, max) of one axis of
+//    one child in a register pair;
+//  * ONE record array: pair records [0, P) and 64-byte leaf-triangle records [P, P + T) -- a child
+//    reference is its record index, so the fetch address is one shift-add for inner and leaf lanes;
+//  * the first 127 records (7 tree levels, ~40 % of the node visits) are served from LDS;
+//  * leaf visits only on every LEAFP-th trip (lanes standing at a leaf wait);
+//  * descend / push / pop as selects instead of nested branches.
+//
+// Lanes or launches outside the proof conditions (direction component zero, > 1 or < 2^-60, tiny or
+// huge origin / scene bounds) run the EXACT instantiation of the step: IEEE divisions and OpenCL's
+// select-form min/max, as the reference writes them.
+#include "uvrt_device.h"
+
+namespace uvrt {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int MAXS6 = 32;                 // extend.cl:43
+constexpr int PS6 = 8;                    // LDS stack entries per lane
+constexpr uint32_t TOP6_MAX = 127;        // records cached in LDS (8 KB)
+
+// {a.x / d, a.y / d} correctly rounded; dy = {d, RN32(1/d)}.  One packed instruction per step, the
+// broadcast of d or y done by op_sel.
+__device__ __forceinline__ v2f div2(v2f a, v2f dy)
+{
+    v2f q0, r, q;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(q0) : "v"(a), "v"(dy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(dy), "v"(q0), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(q) : "v"(r), "v"(dy), "v"(q0));
+    return q;
+}
+
+// {a.x - o.x, a.y - o.x}
+__device__ __forceinline__ v2f sub_lo2(v2f a, v2f o)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(o));
+    return d;
+}
+
+// extend.cl:29-38 from the three (t at min, t at max) pairs: entry distance and hit flag.  No operand
+// is NaN on this path, so v_min/v_max equal OpenCL's y<x?y:x / x<y?y:x.
+__device__ __forceinline__ bool box_fast(v2f tx, v2f ty, v2f tz, float dist, float& tmin)
+{
+    float nx, fx, ny, fy, nz, fz, tmax;
+    asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(tx.x), "v"(tx.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(tx.x), "v"(tx.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ty.x), "v"(ty.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ty.x), "v"(ty.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(nx), "v"(ny), "v"(nz));   // max(max(nx, ny), nz)
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(fx), "v"(fy), "v"(fz));   // min(min(fx, fy), fz)
+    return (tmax >= tmin) & (tmin < dist) & (tmax > 0);
+}
+
+// the reference's own form: IEEE divisions, OpenCL min/max as selects (NaN operands: 0/0)
+__device__ __forceinline__ bool box_exact(float ax1, float ax2, float ay1, float ay2, float az1, float az2,
+                                          float dx, float dy, float dz, float dist, float& tmin_out)
+{
+    const float tx1 = ax1 / dx, tx2 = ax2 / dx;
+    float tmin = tx2 < tx1 ? tx2 : tx1, tmax = tx1 < tx2 ? tx2 : tx1;
+    const float ty1 = ay1 / dy, ty2 = ay2 / dy;
+    const float mny = ty2 < ty1 ? ty2 : ty1, mxy = ty1 < ty2 ? ty2 : ty1;
+    tmin = tmin < mny ? mny : tmin;
+    tmax = mxy < tmax ? mxy : tmax;
+    const float tz1 = az1 / dz, tz2 = az2 / dz;
+    const float mnz = tz2 < tz1 ? tz2 : tz1, mxz = tz1 < tz2 ? tz2 : tz1;
+    tmin = tmin < mnz ? mnz : tmin;
+    tmax = mxz < tmax ? mxz : tmax;
+    tmin_out = tmin;
+    return tmax >= tmin && tmin < dist && tmax > 0;
+}
+
+// RN32(1 / a) for 2^-64 <= |a| < 2^64 (file header)
+__device__ __forceinline__ float rcp_exact(float a)
+{
+    float y0;
+    asm("v_rcp_f32 %0, %1" : "=v"(y0) : "v"(a));
+    const float e = __builtin_fmaf(-a, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+
+// extend.cl:6-27 on a leaf record (v0, e1 = v1 - v0, e2 = v2 - v0, id in v0.w)
+template <bool EXACT>
+__device__ __forceinline__ void tri6(float ox, float oy, float oz, float dx, float dy, float dz, float& dist,
+                                     uint32_t& triID, const float4 v0, const float4 e1, const float4 e2)
+{
+    const float hx = dy * e2.z - dz * e2.y;
+    const float hy = dz * e2.x - dx * e2.z;
+    const float hz = dx * e2.y - dy * e2.x;
+    const float a = e1.x * hx + e1.y * hy + e1.z * hz;
+    if (fabsf(a) < 0.00001f) return;
+    const float f = EXACT ? 1.0f / a : rcp_exact(a);
+    const float sx = ox - v0.x, sy = oy - v0.y, sz = oz - v0.z;
+    const float u = f * (sx * hx + sy * hy + sz * hz);
+    if ((u < 0) | (u > 1)) return;
+    const float qx = sy * e1.z - sz * e1.y;
+    const float qy = sz * e1.x - sx * e1.z;
+    const float qz = sx * e1.y - sy * e1.x;
+    const float v = f * (dx * qx + dy * qy + dz * qz);
+    if ((v < 0) | (u + v > 1)) return;
+    const float tt = f * (e2.x * qx + e2.y * qy + e2.z * qz);
+    if (tt > 0.0001f && tt < dist) {
+        dist = tt;
+        triID = __float_as_uint(v0.w);
+    }
+}
+
+struct Lane6 {
+    v2f px, py, pz;         // {d, RN32(1/d)} per axis
+    v2f po;                 // {origin y, dist}
+    uint32_t triID;
+    uint32_t cur;           // record reference: index | leaf bit + count code, REF_DONE = no ray
+    int sp;
+};
+
+// One traversal step of one lane (extend.cl:44-80): an inner node (both children tested, ordered,
+// descend / push / pop) or -- on a leaf trip -- a leaf (its triangles, pop).
+template <bool EXACT, bool TOP>
+__device__ __forceinline__ void step6(Lane6& L, uint32_t* ovf, const ExtendParams& p,
+                                      uint32_t (*s_stack)[256], const float4* s_top, uint32_t top_pairs,
+                                      bool leaf_trip)
+{
+    const int tid = threadIdx.x;
+    const uint32_t cur = L.cur;
+    const bool is_inner = cur < REF_LEAF_BIT;
+    const bool is_leaf = (cur >= REF_LEAF_BIT) & (cur != REF_DONE) & leaf_trip;
+    const uint32_t idx = cur & REF_FIRST_MASK;          // record index (inner indices are < 2^27 too)
+    const bool in_top = TOP && cur < top_pairs;
+    v4f w0, w1, w2, w3;   // written by the loads below, read only by the lanes that executed them
+    uint32_t spec_top = REF_DONE;
+    if (is_inner | is_leaf) {
+        if (L.sp > 0) spec_top = s_stack[(L.sp - 1) & (PS6 - 1)][tid];
+        if (in_top) {
+            // part q of record r: 16-byte slot q ^ ((r >> 2) & 3) of its 64-byte block
+            const uint32_t a0 = (uint32_t)(uintptr_t)s_top + (cur << 6) + ((cur & 12u) << 2);
+            const uint32_t a1 = a0 ^ 16u, a2 = a0 ^ 32u, a3 = a0 ^ 48u;
+            asm volatile("ds_read_b128 %0, %4\n\t"
+                         "ds_read_b128 %1, %5\n\t"
+                         "ds_read_b128 %2, %6\n\t"
+                         "ds_read_b128 %3, %7\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                         : "memory");
+        } else {
+            const char* recp = (const char*)p.recs + ((uint64_t)idx << 6);
+            asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                         "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                         "global_load_dwordx4 %3, %4, off offset:48\n\t"
+                         "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                         : "v"(recp)
+                         : "memory");
+        }
+    }
+    bool need_pop = is_leaf;
+    if (is_inner) {
+        float d0, d1;
+        bool h0, h1;
+        if (EXACT) {
+            h0 = box_exact(w0.x, w0.y, w2.x - L.po.x, w2.y - L.po.x, w0.z, w0.w, L.px.x, L.py.x, L.pz.x, L.po.y, d0);
+            h1 = box_exact(w1.x, w1.y, w2.z - L.po.x, w2.w - L.po.x, w1.z, w1.w, L.px.x, L.py.x, L.pz.x, L.po.y, d1);
+        } else {
+            const v2f x0 = __builtin_shufflevector(w0, w0, 0, 1), z0 = __builtin_shufflevector(w0, w0, 2, 3);
+            const v2f x1 = __builtin_shufflevector(w1, w1, 0, 1), z1 = __builtin_shufflevector(w1, w1, 2, 3);
+            const v2f y0 = sub_lo2(__builtin_shufflevector(w2, w2, 0, 1), L.po);
+            const v2f y1 = sub_lo2(__builtin_shufflevector(w2, w2, 2, 3), L.po);
+            h0 = box_fast(div2(x0, L.px), div2(y0, L.py), div2(z0, L.pz), L.po.y, d0);
+            h1 = box_fast(div2(x1, L.px), div2(y1, L.py), div2(z1, L.pz), L.po.y, d1);
+        }
+        // extend.cl:56-76 with dist = 1e30f for a missed child: nearer first, farther pushed
+        const float D0 = h0 ? d0 : 1e30f, D1 = h1 ? d1 : 1e30f;
+        const bool sw = D0 > D1;
+        const uint32_t r0 = __float_as_uint(w3.x), r1 = __float_as_uint(w3.y);
+        const uint32_t nearer = sw ? r1 : r0, farther = sw ? r0 : r1;
+        if (h0 & h1) {
+            if (L.sp < PS6) s_stack[L.sp][tid] = farther;
+            else if (L.sp < MAXS6) ovf[L.sp - PS6] = farther;
+            else *p.error_flag = 1u;
+            L.sp = L.sp < MAXS6 ? L.sp + 1 : L.sp;
+        }
+        need_pop = !(h0 | h1);
+        L.cur = nearer;
+    } else if (is_leaf) {                                  // extend.cl:48-55
+        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
+        const uint32_t first = idx - (uint32_t)p.npairs;
+        if (count == 15u) count = p.scene.leaf_count[first];
+        float dist = L.po.y;
+        tri6<EXACT>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+                    make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
+                    make_float4(w2.x, w2.y, w2.z, w2.w));
+        for (uint32_t i = 1; i < count; ++i) {
+            const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
+            tri6<EXACT>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2]);
+        }
+        L.po.y = dist;
+    }
+    if (need_pop) {
+        uint32_t popped = spec_top;                        // REF_DONE when the stack is empty
+        if (L.sp > PS6) popped = ovf[L.sp - 1 - PS6];
+        L.cur = popped;
+        L.sp = L.sp > 0 ? L.sp - 1 : 0;
+    }
+}
+
+template <int LEAFP, bool RECORD, bool TOP>
+__global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
+{
+    __shared__ uint32_t s_stack[PS6][256];                          // 8 KB
+    __shared__ float4 s_top[TOP ? (TOP6_MAX + 1) * 4 : 4];          // 8 KB
+    const uint32_t top_pairs = TOP ? (p.top_pairs < TOP6_MAX ? p.top_pairs : TOP6_MAX) : 0u;
+    if (TOP) {
+        const float4* src = (const float4*)p.recs;
+        for (uint32_t i = threadIdx.x; i < top_pairs * 4u; i += 256u) {
+            const uint32_t rec = i >> 2;
+            s_top[rec * 4u + ((i & 3u) ^ ((rec >> 2) & 3u))] = src[i];
+        }
+        __syncthreads();
+    }
+    uint32_t* const ovf = p.ovf_stack + ((size_t)blockIdx.x * 256 + threadIdx.x) * (MAXS6 - PS6);
+    Lane6 L;
+    L.px = L.py = L.pz = (v2f){1.f, 1.f};
+    L.po = (v2f){0.f, 1e30f};      // dist == 1e30f <=> nothing to deposit
+    L.triID = 0;
+    L.cur = REF_DONE;
+    L.sp = 0;
+    uint32_t slot = 0;
+    bool live = false;             // RECORD: holds a ray whose (dist, triID) has not been written yet
+    unsigned long long special_mask = 0;   // lanes whose ray needs the EXACT step (wave-uniform value)
+    int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
+
+    // wave w traces the 64-ray batches w, w + W, w + 2W, ... (see k_extend_persist)
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t W = gridDim.x * 4u;
+    uint32_t cursor = 0;
+    const uint32_t chunk_end = p.chunk;
+    const uint32_t n32 = (uint32_t)p.n;
+    uint32_t trip = 0;
+
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(L.cur == REF_DONE);
+        const int nidle = __popcll(idle_mask);
+        if (cursor < chunk_end && nidle >= 16) {
+            bool spec = false;
+            if (L.cur == REF_DONE) {
+                // results of the rays these lanes finished since the last refill (extend.cl:94-98)
+                if (RECORD && live && p.hits) {
+                    const uint32_t li = p.order ? p.order[slot] : slot;
+                    p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
+                }
+                if (L.po.y != 1e30f) atomicAdd(&my_counts[L.triID], 1);
+                live = false;
+                L.po.y = 1e30f;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const uint32_t v = cursor + rank;
+                const uint32_t my = ((v >> 6) * W + wave) * 64u + (v & 63u);
+                if (v < chunk_end && my < n32) {
+                    const float4 rec = p.rays[my];
+                    // RN32(RN64(1/d)) = RN32(1/d): 1/d is never within 2^-49 of a binary32 midpoint
+                    L.px = (v2f){rec.x, (float)p.recip[my]};
+                    L.py = (v2f){rec.y, (float)p.recip[p.recip_stride + my]};
+                    L.pz = (v2f){rec.z, (float)p.recip[2 * p.recip_stride + my]};
+                    L.po = (v2f){rec.w, 1e30f};            // generate.cl:34-35
+                    L.triID = 0;
+                    if (RECORD) { slot = my; live = true; }
+                    L.sp = 0;
+                    L.cur = p.root_ref6;
+                    const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
+                    const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
+                    spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
+                           !(adx <= 1.0f) || !(ady <= 1.0f) || !(adz <= 1.0f) ||
+                           (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0;
+                }
+            }
+            cursor += (uint32_t)nidle;
+            special_mask = (special_mask & ~idle_mask) | __ballot(spec);
+        }
+        const unsigned long long act = __ballot(L.cur != REF_DONE);
+        if (act == 0) {
+            if (cursor >= chunk_end) break;
+            continue;
+        }
+        bool leaf_trip = true;
+        if (LEAFP > 1) {
+            leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __ballot(L.cur < REF_LEAF_BIT) == 0;
+            ++trip;
+        }
+        if (special_mask & act) step6<true, TOP>(L, ovf, p, s_stack, s_top, top_pairs, leaf_trip);
+        else step6<false, TOP>(L, ovf, p, s_stack, s_top, top_pairs, leaf_trip);
+    }
+    // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
+    if (RECORD && live && p.hits) {
+        const uint32_t li = p.order ? p.order[slot] : slot;
+        p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
+    }
+    if (L.po.y != 1e30f) atomicAdd(&my_counts[L.triID], 1);           // extend.cl:94-98
+}
+
+// Per-launch node-pair records recs[0, P): the lamp's x and z subtracted from the x / z bounds (the
+// same single f32 subtraction IntersectAABB performs, extend.cl:31,35), one axis of one child per
+// register pair, leaf references re-based to record indices (+P).
+//   w0 = child0 {minx, maxx, minz, maxz}, w1 = child1 likewise,
+//   w2 = {c0 miny, c0 maxy, c1 miny, c1 maxy} (raw), w3 = {ref0, ref1, 0, 0}
+__global__ __launch_bounds__(256) void k_prepare_launch6(const PairRec* __restrict__ pairs,
+                                                         float4* __restrict__ recs, float ox, float oz,
+                                                         int32_t npairs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const PairRec pr = pairs[i];
+    uint32_t r0 = __float_as_uint(pr.c0min_ref0.w), r1 = __float_as_uint(pr.c0max_ref1.w);
+    if (r0 >= REF_LEAF_BIT) r0 += (uint32_t)npairs;
+    if (r1 >= REF_LEAF_BIT) r1 += (uint32_t)npairs;
+    recs[i * 4 + 0] = make_float4(pr.c0min_ref0.x - ox, pr.c0max_ref1.x - ox, pr.c0min_ref0.z - oz, pr.c0max_ref1.z - oz);
+    recs[i * 4 + 1] = make_float4(pr.c1min.x - ox, pr.c1max.x - ox, pr.c1min.z - oz, pr.c1max.z - oz);
+    recs[i * 4 + 2] = make_float4(pr.c0min_ref0.y, pr.c0max_ref1.y, pr.c1min.y, pr.c1max.y);
+    recs[i * 4 + 3] = make_float4(__uint_as_float(r0), __uint_as_float(r1), 0.f, 0.f);
+}
+
+// Leaf-triangle records recs[P, P + T) (64 bytes each), once per scene
+__global__ __launch_bounds__(256) void k_prepare_leaves6(const LeafTri* __restrict__ ltris,
+                                                         float4* __restrict__ recs, int32_t npairs, int32_t T)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    const LeafTri t = ltris[i];
+    float4* out = recs + ((size_t)npairs + i) * 4;
+    out[0] = t.v0_id;
+    out[1] = t.e1;
+    out[2] = t.e2;
+    out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, int32_t T, hipStream_t s)
+{
+    if (T <= 0) return;
+    hipLaunchKernelGGL(k_prepare_leaves6, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, ltris,
+                       (float4*)recs, npairs, T);
+}
+
+// code: bits 0-1 leaf period - 1 (0..3), bit 2 = WITHOUT the top-of-tree cache
+bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream_t s)
+{
+    if (p0.n <= 0) return true;
+    ExtendParams p = p0;
+    const unsigned cus = p.num_cus > 0 ? (unsigned)p.num_cus : 256u;
+    unsigned grid = cus * (unsigned)grid_per_cu;
+    const unsigned need = (unsigned)((p.n + 255) / 256);
+    if (need < grid) grid = need;
+    const uint64_t waves = (uint64_t)grid * 4;
+    p.chunk = (uint32_t)((((uint64_t)p.n + waves - 1) / waves + 63) / 64 * 64);
+    if ((uint64_t)grid * 256 * (MAXS6 - PS6) > p.ovf_capacity) return false;
+    p.root_ref6 = (p.scene.root_ref >= REF_LEAF_BIT && p.scene.root_ref != REF_DONE)
+                      ? p.scene.root_ref + (uint32_t)p.npairs : p.scene.root_ref;
+    if (p.npairs > 0)
+        hipLaunchKernelGGL(k_prepare_launch6, dim3((unsigned)((p.npairs + 255) / 256)), dim3(256), 0, s,
+                           p.scene.pairs, (float4*)p.recs, p.ox, p.oz, p.npairs);
+#define UVRT_L6(LP, TOP)                                                                             \
+    do {                                                                                             \
+        if (p.hits) hipLaunchKernelGGL((k_extend6<LP, true, TOP>), dim3(grid), dim3(256), 0, s, p);    \
+        else hipLaunchKernelGGL((k_extend6<LP, false, TOP>), dim3(grid), dim3(256), 0, s, p);         \
+    } while (0)
+    switch (code & 7) {
+        case 0: UVRT_L6(1, true); break;
+        case 1: UVRT_L6(2, true); break;
+        case 2: UVRT_L6(3, true); break;
+        case 3: UVRT_L6(4, true); break;
+        case 4: UVRT_L6(1, false); break;
+        case 5: UVRT_L6(2, false); break;
+        case 6: UVRT_L6(3, false); break;
+        default: UVRT_L6(4, false); break;
+    }
+#undef UVRT_L6
+    return true;
+}
+
+}  // namespace uvrt
