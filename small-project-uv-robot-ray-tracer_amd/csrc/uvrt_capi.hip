@@ -83,6 +83,7 @@ struct uvrt_ctx {
     int64_t capacity = 0;
     DevBuf rays, keyrank, sorted, order, hits, hist, bin_start, export_buf;
     DevBuf recip, recip_sorted, ovf_stack;   // f64 reciprocals [3][capacity]; persistent-kernel cursor
+    bool recip_valid = false;                  // recip / recip_sorted hold RN64(1/dir) of the current rays
     bool scene_force_exact = false;            // a node bound too tiny / too large for the reciprocal shortcuts
     int32_t hist_bins = 0;
     int64_t last_n = -1;
@@ -138,6 +139,18 @@ void split_bits(int bits, int& bphi, int& by, int& bo)
     bo = bits / 4;
     bphi = (bits - bo + 1) / 2;
     by = bits - bo - bphi;
+}
+
+// Kernel selection (uvrt_set_variant).  0 (default) = extend v6 with the top-of-tree LDS cache and leaf
+// visits every third trip, falling back to the v4 kernel for scenes beyond v6's record numbering;
+// 1-99 = the v1-v4 kernels (launch_extend; 90 = the former default); +100 = the same with IEEE divisions
+// everywhere; 200-299 = v5 (leaf period code + 10 * grid code), 300-399 = v5 with IEEE divisions;
+// 400-499 = v6 (code + 10 * grid code, uvrt_extend6.hip), 500-599 = v6 with IEEE divisions.
+bool variant_is_v6(const uvrt_ctx* c)
+{
+    const bool fits = (size_t)c->npairs + (size_t)c->T < (size_t)MAX_TRIS;
+    if (c->variant == 0) return fits && c->flavour == 0;
+    return c->variant >= 400 && c->variant < 600;
 }
 
 int auto_sort_bits(int64_t n)
@@ -411,7 +424,10 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     GenParams p;
     memset(&p, 0, sizeof p);
     p.rays = c->rays.as<float4>();
-    p.recip = c->recip.as<double>();
+    // extend v6 derives RN32(1/dir) in the kernel; the f64 reciprocals are only written for the
+    // older kernels (and made up by uvrt_extend if the variant is switched after generate)
+    const bool want_recip = !variant_is_v6(c);
+    p.recip = want_recip ? c->recip.as<double>() : nullptr;
     p.recip_stride = c->capacity;
     p.lx = lp[0]; p.ly = lp[1]; p.lz = lp[2];
     p.light_length = light_length;
@@ -439,10 +455,11 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (p.keyrank) {
         launch_scan_bins(c->hist.as<uint32_t>(), c->bin_start.as<uint32_t>(), 1 << bits, c->stream);
         launch_scatter(c->rays.as<float4>(), c->keyrank.as<uint2>(), c->bin_start.as<uint32_t>(),
-                       c->sorted.as<float4>(), c->order.as<uint32_t>(), c->recip_sorted.as<double>(),
-                       c->capacity, n, c->stream);
+                       c->sorted.as<float4>(), c->order.as<uint32_t>(),
+                       want_recip ? c->recip_sorted.as<double>() : nullptr, c->capacity, n, c->stream);
         HIP_TRY(hipGetLastError());
     }
+    c->recip_valid = want_recip;
     c->seed = seed_next;
     c->last_n = n;
     c->last_first = first_gid;
@@ -510,21 +527,23 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         ++c->ev_used;
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    // variants: 0-99 see launch_extend; +100 = the same with IEEE divisions everywhere;
-    // 200-299 = extend v5 (leaf period code + 10 * grid code); 300-399 = v5 with IEEE divisions
-    // 400-499 = extend v6 (code + 10 * grid code, uvrt_extend6.hip); 500-599 = v6 with IEEE divisions
+    const bool v6 = variant_is_v6(c);
     const bool v5 = c->variant >= 200 && c->variant < 400;
-    const bool v6 = c->variant >= 400 && c->variant < 600;
     if ((c->variant >= 100 && c->variant < 200) || (c->variant >= 300 && c->variant < 400) || c->variant >= 500)
         p.force_exact = 1;
-    if (c->flavour != 0 && c->variant != 0)
-        return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default kernel (variant 0) only");
+    if (c->flavour != 0 && c->variant != 0 && c->variant != 90)
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default and the v4 kernel (variants 0, 90) only");
+    if (c->variant >= 400 && c->variant < 600 && (size_t)c->npairs + (size_t)c->T >= (size_t)MAX_TRIS)
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: scene too large for extend v6's record numbering");
+    if (!v6 && !c->recip_valid) {
+        // the rays were generated for v6: make up the f64 reciprocals the older kernels read
+        launch_fill_recip(p.rays, const_cast<double*>(p.recip), p.recip_stride, n, c->stream);
+        c->recip_valid = true;
+    }
     static const int per_cu5[5] = {8, 4, 6, 2, 16};
     const int g5 = (c->variant / 10) % 10;
-    const bool v6_ok = (size_t)c->npairs + (size_t)c->T < (size_t)MAX_TRIS;   // record index fits the reference
-    if (v6 && !v6_ok)
-        return fail(UVRT_ERR_INVALID, "uvrt_extend: scene too large for extend v6's record numbering");
-    if (v6 ? !launch_extend6(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], c->stream)
+    const int code6 = c->variant == 0 ? 2 : c->variant % 10;
+    if (v6 ? !launch_extend6(p, code6, per_cu5[g5 < 5 ? g5 : 0], c->stream)
         : v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], c->stream)
              : !launch_extend(p, c->variant % 100, c->stream))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
@@ -703,6 +722,7 @@ int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
         HIP_TRY(hipMemcpyAsync((char*)c->recip.p + (size_t)k * c->capacity * 8, rec.data() + (size_t)k * n,
                                (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->recip_valid = true;
     c->last_n = n;
     c->last_first = 0;
     c->last_sorted = false;

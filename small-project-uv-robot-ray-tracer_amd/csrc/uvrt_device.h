@@ -92,6 +92,7 @@ void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStr
 void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bin_start,
                     float4* sorted, uint32_t* order, double* recip_sorted, int64_t recip_stride,
                     int64_t n, hipStream_t s);
+void launch_fill_recip(const float4* rays, double* recip, int64_t recip_stride, int64_t n, hipStream_t s);
 // returns false (nothing launched) when the variant's grid would not fit the overflow-stack buffer
 bool launch_extend(const ExtendParams& p, int variant, hipStream_t s);
 // extend v5 (uvrt_extend5.hip): leaf_code 0..3 = leaf visits every 1/2/3/4 trips

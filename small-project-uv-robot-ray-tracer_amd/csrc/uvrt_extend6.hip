@@ -32,26 +32,30 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int MAXS6 = 32;                 // extend.cl:43
 constexpr int PS6 = 8;                    // LDS stack entries per lane
-constexpr uint32_t TOP6_MAX = 127;        // records cached in LDS (8 KB)
+constexpr uint32_t TOP6_MAX = 127;        // records cached in LDS
+constexpr uint32_t TOP6_STRIDE = 80;      // bytes per cached record (64 + 16 padding): 10 KB
 
-// {a.x / d, a.y / d} correctly rounded; dy = {d, RN32(1/d)}.  One packed instruction per step, the
-// broadcast of d or y done by op_sel.
-__device__ __forceinline__ v2f div2(v2f a, v2f dy)
+// The six slab distances of one child box (extend.cl:31-37), correctly rounded:
+//   t = a / d  as  q0 = a * y;  r = fma(-d, q0, a);  q = fma(r, y, q0),   y = RN32(1/d)
+// for the three (min, max) numerator pairs x, z (already a = b - o) and y (raw bounds: the ray's
+// origin y is subtracted first).  px/py/pz = {d, y} per axis, po = {origin y, .}; every step is one
+// packed instruction with the broadcast of d, y or o done by op_sel.  One asm block so that the
+// three chains are interleaved by hand and need exactly three temporary register pairs.
+__device__ __forceinline__ void slabs6(v2f& x, v2f& y, v2f& z, v2f px, v2f py, v2f pz, v2f po)
 {
-    v2f q0, r, q;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(q0) : "v"(a), "v"(dy));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
-        : "=v"(r) : "v"(dy), "v"(q0), "v"(a));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(q) : "v"(r), "v"(dy), "v"(q0));
-    return q;
-}
-
-// {a.x - o.x, a.y - o.x}
-__device__ __forceinline__ v2f sub_lo2(v2f a, v2f o)
-{
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(o));
-    return d;
+    v2f tx, ty, tz;
+    asm("v_pk_add_f32 %[y], %[y], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[tx], %[x], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[tz], %[z], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[ty], %[y], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_fma_f32 %[x], %[px], %[tx], %[x] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[z], %[pz], %[tz], %[z] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[y], %[py], %[ty], %[y] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[x], %[x], %[px], %[tx] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[z], %[z], %[pz], %[tz] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[y], %[y], %[py], %[ty] op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz)
+        : [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [po] "v"(po));
 }
 
 // extend.cl:29-38 from the three (t at min, t at max) pairs: entry distance and hit flag.  No operand
@@ -98,16 +102,18 @@ __device__ __forceinline__ float rcp_exact(float a)
 }
 
 // extend.cl:6-27 on a leaf record (v0, e1 = v1 - v0, e2 = v2 - v0, id in v0.w)
-template <bool EXACT>
 __device__ __forceinline__ void tri6(float ox, float oy, float oz, float dx, float dy, float dz, float& dist,
-                                     uint32_t& triID, const float4 v0, const float4 e1, const float4 e2)
+                                     uint32_t& triID, const float4 v0, const float4 e1, const float4 e2,
+                                     bool exact)
 {
     const float hx = dy * e2.z - dz * e2.y;
     const float hy = dz * e2.x - dx * e2.z;
     const float hz = dx * e2.y - dy * e2.x;
     const float a = e1.x * hx + e1.y * hy + e1.z * hz;
     if (fabsf(a) < 0.00001f) return;
-    const float f = EXACT ? 1.0f / a : rcp_exact(a);
+    float f;
+    if (exact) f = 1.0f / a;         // wave-uniform
+    else f = rcp_exact(a);
     const float sx = ox - v0.x, sy = oy - v0.y, sz = oz - v0.z;
     const float u = f * (sx * hx + sy * hy + sz * hz);
     if ((u < 0) | (u > 1)) return;
@@ -133,59 +139,81 @@ struct Lane6 {
 
 // One traversal step of one lane (extend.cl:44-80): an inner node (both children tested, ordered,
 // descend / push / pop) or -- on a leaf trip -- a leaf (its triangles, pop).
-template <bool EXACT, bool TOP>
-__device__ __forceinline__ void step6(Lane6& L, uint32_t* ovf, const ExtendParams& p,
-                                      uint32_t (*s_stack)[256], const float4* s_top, uint32_t top_pairs,
-                                      bool leaf_trip)
+// Stack entries 8..31 of this thread live in global memory (0.02 % of pushes on the test room).  The
+// pointer is rebuilt from scratch where it is needed -- opaque to the compiler, which would otherwise
+// keep it in two VGPRs (or a scratch slot) across the whole loop.
+__device__ __forceinline__ uint32_t* ovf_ptr(const ExtendParams& p)
 {
-    const int tid = threadIdx.x;
+    uint32_t lane, wv;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(wv) : "s"(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)));
+    return p.ovf_stack + ((size_t)blockIdx.x * 256 + wv * 64 + lane) * (MAXS6 - PS6);
+}
+
+// `exact` is wave-uniform: the record fetch and the descend / push / pop logic are common, only the
+// arithmetic of the box and triangle tests differs.
+template <bool TOP>
+__device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t stack_base,
+                                      const float4* s_top, uint32_t top_pairs, bool leaf_trip, bool exact)
+{
     const uint32_t cur = L.cur;
     const bool is_inner = cur < REF_LEAF_BIT;
     const bool is_leaf = (cur >= REF_LEAF_BIT) & (cur != REF_DONE) & leaf_trip;
     const uint32_t idx = cur & REF_FIRST_MASK;          // record index (inner indices are < 2^27 too)
     const bool in_top = TOP && cur < top_pairs;
-    v4f w0, w1, w2, w3;   // written by the loads below, read only by the lanes that executed them
-    uint32_t spec_top = REF_DONE;
-    if (is_inner | is_leaf) {
-        if (L.sp > 0) spec_top = s_stack[(L.sp - 1) & (PS6 - 1)][tid];
-        if (in_top) {
-            // part q of record r: 16-byte slot q ^ ((r >> 2) & 3) of its 64-byte block
-            const uint32_t a0 = (uint32_t)(uintptr_t)s_top + (cur << 6) + ((cur & 12u) << 2);
-            const uint32_t a1 = a0 ^ 16u, a2 = a0 ^ 32u, a3 = a0 ^ 48u;
-            asm volatile("ds_read_b128 %0, %4\n\t"
-                         "ds_read_b128 %1, %5\n\t"
-                         "ds_read_b128 %2, %6\n\t"
-                         "ds_read_b128 %3, %7\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
-                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
-                         : "memory");
-        } else {
-            const char* recp = (const char*)p.recs + ((uint64_t)idx << 6);
-            asm volatile("global_load_dwordx4 %0, %4, off\n\t"
-                         "global_load_dwordx4 %1, %4, off offset:16\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:32\n\t"
-                         "global_load_dwordx4 %3, %4, off offset:48\n\t"
-                         "s_waitcnt vmcnt(0) lgkmcnt(0)"
-                         : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
-                         : "v"(recp)
-                         : "memory");
-        }
+    // ONE asm block fetches the 64-byte record of every stepping lane -- from the LDS top-of-tree
+    // cache or from global memory, chosen by exec masks -- and the lane's stack top, so that both
+    // sources write the same registers (hipcc otherwise merges the two branches with v_mov chains).
+    v4f w0, w1, w2, w3;
+    uint32_t spec_top = REF_DONE;                       // stays REF_DONE when the stack is empty
+    // stack entry sp - 1 of this lane (lanes with sp == 0 are masked off); entry sp is 1024 bytes on
+    const uint32_t sa = stack_base + ((uint32_t)L.sp << 10);
+    {
+        const bool go = is_inner | is_leaf;
+        const unsigned long long m_top = __ballot(in_top & go);
+        const unsigned long long m_glob = __ballot(go & !in_top);
+        const unsigned long long m_stk = __ballot(go & (L.sp > 0));
+        // LDS copy of record r at byte 80 r: the 16 padding bytes spread the lanes of a ds_read_b128
+        // over sixteen 4-bank windows (20 r mod 64) instead of four
+        const uint32_t a0 = (uint32_t)(uintptr_t)s_top + cur * TOP6_STRIDE;
+        const char* recp = (const char*)p.recs + ((uint64_t)idx << 6);
+        unsigned long long save;
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     "s_mov_b64 exec, %[mstk]\n\t"
+                     "ds_read_b32 %[st], %[sa]\n\t"
+                     "s_mov_b64 exec, %[mtop]\n\t"
+                     "ds_read_b128 %[w0], %[a0]\n\t"
+                     "ds_read_b128 %[w1], %[a0] offset:16\n\t"
+                     "ds_read_b128 %[w2], %[a0] offset:32\n\t"
+                     "ds_read_b128 %[w3], %[a0] offset:48\n\t"
+                     "s_mov_b64 exec, %[mglob]\n\t"
+                     "global_load_dwordx4 %[w0], %[rp], off\n\t"
+                     "global_load_dwordx4 %[w1], %[rp], off offset:16\n\t"
+                     "global_load_dwordx4 %[w2], %[rp], off offset:32\n\t"
+                     "global_load_dwordx4 %[w3], %[rp], off offset:48\n\t"
+                     "s_mov_b64 exec, %[save]\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [st] "+v"(spec_top),
+                       [save] "=&s"(save)
+                     : [a0] "v"(a0), [sa] "v"(sa), [rp] "v"(recp),
+                       [mtop] "s"(m_top), [mglob] "s"(m_glob), [mstk] "s"(m_stk)
+                     : "memory");
     }
     bool need_pop = is_leaf;
     if (is_inner) {
         float d0, d1;
         bool h0, h1;
-        if (EXACT) {
+        if (exact) {
             h0 = box_exact(w0.x, w0.y, w2.x - L.po.x, w2.y - L.po.x, w0.z, w0.w, L.px.x, L.py.x, L.pz.x, L.po.y, d0);
             h1 = box_exact(w1.x, w1.y, w2.z - L.po.x, w2.w - L.po.x, w1.z, w1.w, L.px.x, L.py.x, L.pz.x, L.po.y, d1);
         } else {
-            const v2f x0 = __builtin_shufflevector(w0, w0, 0, 1), z0 = __builtin_shufflevector(w0, w0, 2, 3);
-            const v2f x1 = __builtin_shufflevector(w1, w1, 0, 1), z1 = __builtin_shufflevector(w1, w1, 2, 3);
-            const v2f y0 = sub_lo2(__builtin_shufflevector(w2, w2, 0, 1), L.po);
-            const v2f y1 = sub_lo2(__builtin_shufflevector(w2, w2, 2, 3), L.po);
-            h0 = box_fast(div2(x0, L.px), div2(y0, L.py), div2(z0, L.pz), L.po.y, d0);
-            h1 = box_fast(div2(x1, L.px), div2(y1, L.py), div2(z1, L.pz), L.po.y, d1);
+            v2f x0 = __builtin_shufflevector(w0, w0, 0, 1), z0 = __builtin_shufflevector(w0, w0, 2, 3);
+            v2f x1 = __builtin_shufflevector(w1, w1, 0, 1), z1 = __builtin_shufflevector(w1, w1, 2, 3);
+            v2f y0 = __builtin_shufflevector(w2, w2, 0, 1), y1 = __builtin_shufflevector(w2, w2, 2, 3);
+            slabs6(x0, y0, z0, L.px, L.py, L.pz, L.po);
+            h0 = box_fast(x0, y0, z0, L.po.y, d0);
+            slabs6(x1, y1, z1, L.px, L.py, L.pz, L.po);
+            h1 = box_fast(x1, y1, z1, L.po.y, d1);
         }
         // extend.cl:56-76 with dist = 1e30f for a missed child: nearer first, farther pushed
         const float D0 = h0 ? d0 : 1e30f, D1 = h1 ? d1 : 1e30f;
@@ -193,8 +221,8 @@ __device__ __forceinline__ void step6(Lane6& L, uint32_t* ovf, const ExtendParam
         const uint32_t r0 = __float_as_uint(w3.x), r1 = __float_as_uint(w3.y);
         const uint32_t nearer = sw ? r1 : r0, farther = sw ? r0 : r1;
         if (h0 & h1) {
-            if (L.sp < PS6) s_stack[L.sp][tid] = farther;
-            else if (L.sp < MAXS6) ovf[L.sp - PS6] = farther;
+            if (L.sp < PS6) asm volatile("ds_write_b32 %0, %1 offset:1024" : : "v"(sa), "v"(farther) : "memory");
+            else if (L.sp < MAXS6) ovf_ptr(p)[L.sp - PS6] = farther;
             else *p.error_flag = 1u;
             L.sp = L.sp < MAXS6 ? L.sp + 1 : L.sp;
         }
@@ -205,18 +233,18 @@ __device__ __forceinline__ void step6(Lane6& L, uint32_t* ovf, const ExtendParam
         const uint32_t first = idx - (uint32_t)p.npairs;
         if (count == 15u) count = p.scene.leaf_count[first];
         float dist = L.po.y;
-        tri6<EXACT>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
-                    make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
-                    make_float4(w2.x, w2.y, w2.z, w2.w));
+        tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+             make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
+             make_float4(w2.x, w2.y, w2.z, w2.w), exact);
         for (uint32_t i = 1; i < count; ++i) {
             const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
-            tri6<EXACT>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2]);
+            tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
         }
         L.po.y = dist;
     }
     if (need_pop) {
         uint32_t popped = spec_top;                        // REF_DONE when the stack is empty
-        if (L.sp > PS6) popped = ovf[L.sp - 1 - PS6];
+        if (L.sp > PS6) popped = ovf_ptr(p)[L.sp - 1 - PS6];
         L.cur = popped;
         L.sp = L.sp > 0 ? L.sp - 1 : 0;
     }
@@ -226,17 +254,18 @@ template <int LEAFP, bool RECORD, bool TOP>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
     __shared__ uint32_t s_stack[PS6][256];                          // 8 KB
-    __shared__ float4 s_top[TOP ? (TOP6_MAX + 1) * 4 : 4];          // 8 KB
+    __shared__ float4 s_top[TOP ? (TOP6_MAX + 1) * 5 : 4];          // 10 KB
     const uint32_t top_pairs = TOP ? (p.top_pairs < TOP6_MAX ? p.top_pairs : TOP6_MAX) : 0u;
     if (TOP) {
         const float4* src = (const float4*)p.recs;
         for (uint32_t i = threadIdx.x; i < top_pairs * 4u; i += 256u) {
             const uint32_t rec = i >> 2;
-            s_top[rec * 4u + ((i & 3u) ^ ((rec >> 2) & 3u))] = src[i];
+            s_top[rec * 5u + (i & 3u)] = src[i];
         }
         __syncthreads();
     }
-    uint32_t* const ovf = p.ovf_stack + ((size_t)blockIdx.x * 256 + threadIdx.x) * (MAXS6 - PS6);
+    // LDS byte address of this lane's stack entry -1 (entry e at + 1024 (e + 1))
+    const uint32_t stack_base = (uint32_t)(uintptr_t)&s_stack[0][threadIdx.x] - 1024u;
     Lane6 L;
     L.px = L.py = L.pz = (v2f){1.f, 1.f};
     L.po = (v2f){0.f, 1e30f};      // dist == 1e30f <=> nothing to deposit
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
 
     // wave w traces the 64-ray batches w, w + W, w + 2W, ... (see k_extend_persist)
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t wave = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t W = gridDim.x * 4u;
     uint32_t cursor = 0;
     const uint32_t chunk_end = p.chunk;
@@ -276,10 +305,11 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                 const uint32_t my = ((v >> 6) * W + wave) * 64u + (v & 63u);
                 if (v < chunk_end && my < n32) {
                     const float4 rec = p.rays[my];
-                    // RN32(RN64(1/d)) = RN32(1/d): 1/d is never within 2^-49 of a binary32 midpoint
-                    L.px = (v2f){rec.x, (float)p.recip[my]};
-                    L.py = (v2f){rec.y, (float)p.recip[p.recip_stride + my]};
-                    L.pz = (v2f){rec.z, (float)p.recip[2 * p.recip_stride + my]};
+                    // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
+                    // and never use y)
+                    L.px = (v2f){rec.x, rcp_exact(rec.x)};
+                    L.py = (v2f){rec.y, rcp_exact(rec.y)};
+                    L.pz = (v2f){rec.z, rcp_exact(rec.z)};
                     L.po = (v2f){rec.w, 1e30f};            // generate.cl:34-35
                     L.triID = 0;
                     if (RECORD) { slot = my; live = true; }
@@ -305,8 +335,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __ballot(L.cur < REF_LEAF_BIT) == 0;
             ++trip;
         }
-        if (special_mask & act) step6<true, TOP>(L, ovf, p, s_stack, s_top, top_pairs, leaf_trip);
-        else step6<false, TOP>(L, ovf, p, s_stack, s_top, top_pairs, leaf_trip);
+        step6<TOP>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0);
     }
     // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
     if (RECORD && live && p.hits) {

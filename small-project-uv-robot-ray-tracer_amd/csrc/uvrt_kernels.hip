@@ -158,6 +158,18 @@ __global__ __launch_bounds__(256) void k_scatter(const float4* __restrict__ rays
     }
 }
 
+// RN64(1/dir) for rays that were generated without them (extend v6 does not need them)
+__global__ __launch_bounds__(256) void k_fill_recip(const float4* __restrict__ rays, double* __restrict__ recip,
+                                                    int64_t recip_stride, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = rays[i];
+    recip[i] = 1.0 / (double)r.x;
+    recip[recip_stride + i] = 1.0 / (double)r.y;
+    recip[2 * recip_stride + i] = 1.0 / (double)r.z;
+}
+
 // ------------------------------------------------------------------- extend, cl/extend.cl
 
 // OpenCL min/max on floats: min(x,y) = y<x ? y : x, max(x,y) = x<y ? y : x.  They differ from
@@ -967,6 +979,12 @@ void launch_generate(const GenParams& p, hipStream_t s)
 {
     if (p.n <= 0) return;
     hipLaunchKernelGGL(k_generate, dim3(blocks_for(p.n, 256)), dim3(256), 0, s, p);
+}
+
+void launch_fill_recip(const float4* rays, double* recip, int64_t recip_stride, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fill_recip, dim3(blocks_for(n, 256)), dim3(256), 0, s, rays, recip, recip_stride, n);
 }
 
 void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStream_t s)
