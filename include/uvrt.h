@@ -119,7 +119,10 @@ int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
  * run live on the same GPU, bit for bit.  Everything else (slab test, traversal, deposit) is
  * common to both flavours. */
 int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
-/* extend kernel variant: 0 = default; see DESIGN.md */
+/* extend kernel variant (developer / A-B knob; every variant is bit-exact): 0 = default (extend v6);
+ * 1-99 = the v1-v4 kernels (90 = the v4 default of earlier builds); 200-399 = v5; 400-899 = v6
+ * with explicit leaf period / top cache / grid / refill settings; +100 on 0-99, 300-399 and 500-599
+ * = IEEE divisions everywhere.  See DESIGN.md section 4. */
 int uvrt_set_variant(uvrt_ctx* ctx, int32_t variant);
 
 /* ---- test / interop hooks ---- */

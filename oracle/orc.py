@@ -80,6 +80,8 @@ def lib():
         L.orc_floor_height.argtypes = [C.c_void_p, C.c_int32]
         L.orc_set_flavour.restype = None
         L.orc_set_flavour.argtypes = [C.c_int]
+        L.orc_extend_steps.restype = None
+        L.orc_extend_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bvh_build.restype = C.c_int32
         L.orc_bvh_build.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = L
@@ -209,6 +211,13 @@ def extend(temp, tris, rays, nodes, triIdx, nthreads=0):
     lib().orc_extend(_p(temp), _p(tris), _p(rays), rays.size, _p(nodes), _p(triIdx),
                      C.byref(st), int(nthreads))
     return st.as_dict()
+
+
+def extend_steps(tris, rays, nodes, triIdx):
+    """node visits per ray (analysis helper)"""
+    steps = np.zeros(rays.size, dtype=np.uint16)
+    lib().orc_extend_steps(_p(tris), _p(rays), rays.size, _p(nodes), _p(triIdx), _p(steps))
+    return steps
 
 
 def accumulate(photonMap, maxPhotonMap, temp, timeStep):

@@ -258,6 +258,21 @@ void orc_extend(int32_t* tempPhotonMap, const orc_tri* tris, orc_ray* rays, int6
     if (stats) *stats = total;
 }
 
+/* node visits (traversal steps) of each ray -- analysis helper for the wave-scheduler model in
+ * tests/tools/wave_model.py; rays are not modified */
+void orc_extend_steps(const orc_tri* tris, const orc_ray* rays, int64_t n, const orc_node* nodes,
+                      const uint32_t* triIdx, uint16_t* steps)
+{
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < n; i++) {
+        orc_ray r = rays[i];
+        orc_stats st;
+        memset(&st, 0, sizeof st);
+        bvh_intersect(&r, tris, nodes, triIdx, &st);
+        steps[i] = (uint16_t)(st.node_visits > 65535 ? 65535 : st.node_visits);
+    }
+}
+
 /* ------------------------------------------------- accumulate / reset / shade kernels */
 
 void orc_accumulate(double* photonMap, double* maxPhotonMap, int32_t* temp, float timeStep,

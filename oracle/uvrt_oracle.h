@@ -90,6 +90,10 @@ void orc_generate(orc_ray* rays, int64_t first, int64_t n, const float lightPos[
  *     oracle/_ref/ref_extend.co.  Used to compare bit for bit with those kernels on the GPU. */
 void orc_set_flavour(int flavour);
 
+/* analysis helper: node visits per ray (rays untouched) */
+void orc_extend_steps(const orc_tri* tris, const orc_ray* rays, int64_t n, const orc_node* nodes,
+                      const uint32_t* triIdx, uint16_t* steps);
+
 /* cl/extend.cl:85-99 over n rays (OpenMP over rays; counts are order independent).
  * stats may be NULL. nthreads <= 0 -> OpenMP default. */
 void orc_extend(int32_t* tempPhotonMap, const orc_tri* tris, orc_ray* rays, int64_t n,

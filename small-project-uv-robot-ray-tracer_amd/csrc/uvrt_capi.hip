@@ -146,11 +146,12 @@ void split_bits(int bits, int& bphi, int& by, int& bo)
 // 1-99 = the v1-v4 kernels (launch_extend; 90 = the former default); +100 = the same with IEEE divisions
 // everywhere; 200-299 = v5 (leaf period code + 10 * grid code), 300-399 = v5 with IEEE divisions;
 // 400-499 = v6 (code + 10 * grid code, uvrt_extend6.hip), 500-599 = v6 with IEEE divisions.
+// 600-899 = v6 like 400-499 with the refill threshold 8 / 24 / 4 idle lanes instead of 16.
 bool variant_is_v6(const uvrt_ctx* c)
 {
     const bool fits = (size_t)c->npairs + (size_t)c->T < (size_t)MAX_TRIS;
     if (c->variant == 0) return fits && c->flavour == 0;
-    return c->variant >= 400 && c->variant < 600;
+    return c->variant >= 400 && c->variant < 900;
 }
 
 int auto_sort_bits(int64_t n)
@@ -189,6 +190,10 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (c->num_cus > 256) c->num_cus = 256;   // the overflow-stack buffer is sized for 256 CUs x 16 workgroups
+    if (const char* e = getenv("UVRT_REPLICAS")) {   // developer knob: deposit replicas of tempPhotonMap
+        const int r = atoi(e);
+        if (r >= 1 && r <= 64) c->replicas_knob = r;
+    }
     HIP_TRY(hipSetDevice(device_id));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -529,11 +534,13 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     }
     const bool v6 = variant_is_v6(c);
     const bool v5 = c->variant >= 200 && c->variant < 400;
-    if ((c->variant >= 100 && c->variant < 200) || (c->variant >= 300 && c->variant < 400) || c->variant >= 500)
+    if ((c->variant >= 100 && c->variant < 200) || (c->variant >= 300 && c->variant < 400) ||
+        (c->variant >= 500 && c->variant < 600))
         p.force_exact = 1;
+    p.refill_min = c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
     if (c->flavour != 0 && c->variant != 0 && c->variant != 90)
         return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default and the v4 kernel (variants 0, 90) only");
-    if (c->variant >= 400 && c->variant < 600 && (size_t)c->npairs + (size_t)c->T >= (size_t)MAX_TRIS)
+    if (c->variant >= 400 && c->variant < 900 && (size_t)c->npairs + (size_t)c->T >= (size_t)MAX_TRIS)
         return fail(UVRT_ERR_INVALID, "uvrt_extend: scene too large for extend v6's record numbering");
     if (!v6 && !c->recip_valid) {
         // the rays were generated for v6: make up the f64 reciprocals the older kernels read

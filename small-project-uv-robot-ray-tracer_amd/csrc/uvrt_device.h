@@ -83,6 +83,7 @@ struct ExtendParams {
     void* lpairs;            // extend v5: per-launch node-pair records (uvrt_extend5.hip), npairs x 64 B
     int32_t npairs;
     void* recs;              // extend v6: [npairs] per-launch pair records + [T] leaf records, 64 B each
+    int32_t refill_min;      // extend v6: idle lanes that trigger a refill (16)
     uint32_t root_ref6;      // root reference in v6's record numbering (set by launch_extend6)
 };
 

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     for (;;) {
         const unsigned long long idle_mask = __ballot(L.cur == REF_DONE);
         const int nidle = __popcll(idle_mask);
-        if (cursor < chunk_end && nidle >= 16) {
+        if (cursor < chunk_end && nidle >= p.refill_min) {
             bool spec = false;
             if (L.cur == REF_DONE) {
                 // results of the rays these lanes finished since the last refill (extend.cl:94-98)
