@@ -67,3 +67,65 @@ def test_special_values():
     a = np.array([0.0, -0.0, 1e30, -1e30, 3e38, 1.0, 1e-30, 2.0 ** -100, 5.0], dtype=np.float32)
     for dv in (1.0, -1.0, 2.0 ** -126, -(2.0 ** -126), 2.0 ** -149, 1e-20, 0.3, -0.7):
         assert_same(a, np.full(a.shape, dv, dtype=np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# extend v5/v6: the packed f32 form  q0 = a*y; r = fma(-d, q0, a); q = fma(r, y, q0),  y = RN32(1/d)
+# (csrc/uvrt_extend6.hip).  The proof is the exhaustive GPU run (tests/tools/div3_exhaustive.hip,
+# profiles/r01_div3_exhaustive.log); this is the same check on the CPU (glibc fmaf is exact) over
+# random, extreme-divisor and next-to-midpoint operands.
+_C_SRC = r"""
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline uint64_t rng(uint64_t* s) { *s ^= *s << 13; *s ^= *s >> 7; *s ^= *s << 17; return *s; }
+long check(long n, uint64_t seed)
+{
+    long bad = 0;
+    uint64_t s = seed;
+    for (long i = 0; i < n; i++) {
+        uint64_t x = rng(&s), y = rng(&s);
+        int mode = (int)(i & 7);
+        uint32_t md = (uint32_t)(y & 0x7fffff);
+        if (mode == 1) md |= 0x7ffff0;                 /* divisor significand next to all ones */
+        if (mode == 2) md &= 0xf;                      /* ... next to a power of two */
+        int ed = 127 - (int)((y >> 23) % 40);
+        float d = u2f(((uint32_t)((y >> 63) & 1) << 31) | ((uint32_t)ed << 23) | md);
+        if (fabsf(d) > 1.0f) d = 1.0f;
+        float a;
+        if (mode >= 3) {                               /* quotient next to a rounding midpoint */
+            uint32_t mq = (uint32_t)(x & 0x7fffff);
+            int eq = 127 - 20 + (int)((x >> 23) % 40);
+            float q = u2f(((uint32_t)eq << 23) | mq);
+            double mid = (double)q + 0.5 * (double)(u2f(f2u(q) + 1) - q);
+            a = (float)(mid * (double)d);
+            a = u2f(f2u(a) + (uint32_t)((int)((x >> 40) % 5) - 2));
+        } else {
+            uint32_t ma = (uint32_t)(x & 0x7fffff);
+            int ea = 127 - 30 + (int)((x >> 23) % 50);
+            a = u2f(((uint32_t)((x >> 63) & 1) << 31) | ((uint32_t)ea << 23) | ma);
+        }
+        float ex = a / d;
+        if (!isfinite(ex) || fabsf(ex) < 1.2e-38f) continue;
+        float yy = (float)(1.0 / (double)d);
+        float q0 = a * yy, r = fmaf(-d, q0, a), q = fmaf(r, yy, q0);
+        if (f2u(q) != f2u(ex)) bad++;
+    }
+    return bad;
+}
+"""
+
+
+def test_packed_three_instruction_division_equals_ieee_quotient(tmp_path):
+    import ctypes
+    import subprocess
+    src = tmp_path / "div3.c"
+    src.write_text(_C_SRC)
+    lib = tmp_path / "libdiv3.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(lib), str(src), "-lm"])
+    L = ctypes.CDLL(str(lib))
+    L.check.restype = ctypes.c_long
+    L.check.argtypes = [ctypes.c_long, ctypes.c_uint64]
+    assert L.check(30_000_000, 88172645463325252) == 0
