@@ -203,9 +203,12 @@ def main():
         rt.ctx.seed = 0                       # every step is the same computation (fresh-Init SEED)
         rt.ResetDosageMap()
         rt.set_shard(rank, world)             # restart the global launch index
-        for _ in range(rt.maxIterations):     # myapp.cpp:156-163
+        for it in range(rt.maxIterations):    # myapp.cpp:156-163
             rt.ComputeDosageMap()
-            rt.Shade()
+            # one lamp => launch `it` belongs to rank it % world: every rank shades after each of ITS
+            # launches (the per-GPU work of the N = 1 step), not after the launches it skipped
+            if world == 1 or it % world == rank:
+                rt.Shade()
             rt.currIterations = rt.currIterations + 1
         if reducer is not None:
             reducer()

@@ -90,6 +90,11 @@ int uvrt_compute_dosage(uvrt_ctx* ctx, int32_t which_map, int32_t photons_per_li
 int uvrt_dosage_to_color(uvrt_ctx* ctx, float min_value, int32_t threshold_view,
                          int32_t tri_count);
 
+/* RayTracer::Shade's kernel pair in one launch (raytracer.cpp:96-118): computeDosage followed by
+ * dosageToColor over tri_count triangles, same arithmetic, the dose buffer is written as well */
+int uvrt_shade(uvrt_ctx* ctx, int32_t which_map, int32_t photons_per_light, float scaled_power,
+               float min_value, int32_t threshold_view, int32_t tri_count);
+
 /* clFinish(Kernel::GetQueue()) (myapp.cpp:165, raytracer.cpp:202); also reports a traversal
  * stack overflow raised by any extend since the last sync. */
 int uvrt_sync(uvrt_ctx* ctx);

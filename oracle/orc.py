@@ -29,10 +29,11 @@ assert RAY_DT.itemsize == 32 and NODE_DT.itemsize == 32
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("aabb_tests", C.c_uint64),
-                ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("max_stack", C.c_uint32)]
+                ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("max_stack", C.c_uint32),
+                ("visit_hist", C.c_void_p)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "visit_hist"}
 
 
 def build():
@@ -82,6 +83,8 @@ def lib():
         L.orc_set_flavour.argtypes = [C.c_int]
         L.orc_extend_steps.restype = None
         L.orc_extend_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_extend_visit_hist.restype = None
+        L.orc_extend_visit_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bvh_build.restype = C.c_int32
         L.orc_bvh_build.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = L
@@ -218,6 +221,13 @@ def extend_steps(tris, rays, nodes, triIdx):
     steps = np.zeros(rays.size, dtype=np.uint16)
     lib().orc_extend_steps(_p(tris), _p(rays), rays.size, _p(nodes), _p(triIdx), _p(steps))
     return steps
+
+
+def extend_visit_hist(tris, rays, nodes, triIdx):
+    """visits per node index (analysis helper)"""
+    hist = np.zeros(nodes.size, dtype=np.uint32)
+    lib().orc_extend_visit_hist(_p(tris), _p(rays), rays.size, _p(nodes), _p(triIdx), _p(hist))
+    return hist
 
 
 def accumulate(photonMap, maxPhotonMap, temp, timeStep):

@@ -192,6 +192,7 @@ static inline void bvh_intersect(orc_ray* ray, const orc_tri* tri, const orc_nod
     uint32_t stackPtr = 0;
     while (1) {
         st->node_visits++;
+        if (st->visit_hist) __atomic_fetch_add(&st->visit_hist[node - bvhNode], 1u, __ATOMIC_RELAXED);
         if (node->triCount > 0) {
             for (uint32_t i = 0; i < (uint32_t)node->triCount; i++) {
                 uint32_t triID = triIdx[node->leftFirst + i];
@@ -270,6 +271,20 @@ void orc_extend_steps(const orc_tri* tris, const orc_ray* rays, int64_t n, const
         memset(&st, 0, sizeof st);
         bvh_intersect(&r, tris, nodes, triIdx, &st);
         steps[i] = (uint16_t)(st.node_visits > 65535 ? 65535 : st.node_visits);
+    }
+}
+
+/* visits per node index over n rays -- analysis helper (which tree levels a cache should hold) */
+void orc_extend_visit_hist(const orc_tri* tris, const orc_ray* rays, int64_t n, const orc_node* nodes,
+                           const uint32_t* triIdx, uint32_t* hist)
+{
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < n; i++) {
+        orc_ray r = rays[i];
+        orc_stats st;
+        memset(&st, 0, sizeof st);
+        st.visit_hist = hist;
+        bvh_intersect(&r, tris, nodes, triIdx, &st);
     }
 }
 

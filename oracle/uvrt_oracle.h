@@ -61,6 +61,7 @@ typedef struct {
     uint64_t tri_tests;     /* calls of IntersectTri */
     uint64_t hits;          /* rays with dist != 1e30f */
     uint32_t max_stack;     /* deepest stackPtr seen */
+    uint32_t* visit_hist;   /* optional: visits per node index (analysis helper), NULL otherwise */
 } orc_stats;
 
 /* cl/tools.cl:2-4 */
@@ -93,6 +94,9 @@ void orc_set_flavour(int flavour);
 /* analysis helper: node visits per ray (rays untouched) */
 void orc_extend_steps(const orc_tri* tris, const orc_ray* rays, int64_t n, const orc_node* nodes,
                       const uint32_t* triIdx, uint16_t* steps);
+
+void orc_extend_visit_hist(const orc_tri* tris, const orc_ray* rays, int64_t n, const orc_node* nodes,
+                           const uint32_t* triIdx, uint32_t* hist);
 
 /* cl/extend.cl:85-99 over n rays (OpenMP over rays; counts are order independent).
  * stats may be NULL. nthreads <= 0 -> OpenMP default. */

@@ -36,6 +36,7 @@ SYMBOLS = [
     ("uvrt_accumulate", C.c_int, [_vp, _f32, _i32]),
     ("uvrt_compute_dosage", C.c_int, [_vp, _i32, _i32, _f32, _i32]),
     ("uvrt_dosage_to_color", C.c_int, [_vp, _f32, _i32, _i32]),
+    ("uvrt_shade", C.c_int, [_vp, _i32, _i32, _f32, _f32, _i32, _i32]),
     ("uvrt_sync", C.c_int, [_vp]),
     ("uvrt_read_dosage", C.c_int, [_vp, _vp, _i32, _i32]),
     ("uvrt_read_color", C.c_int, [_vp, _vp, _i32, _i32]),
@@ -151,6 +152,11 @@ class Ctx:
         self._ck(self._L.uvrt_compute_dosage(self._h, int(which), int(photons_per_light),
                                              float(np.float32(scaled_power)),
                                              self.T if tri_count is None else int(tri_count)))
+
+    def shade(self, which, photons_per_light, scaled_power, min_value, threshold_view, tri_count=None):
+        self._ck(self._L.uvrt_shade(self._h, int(which), int(photons_per_light), float(np.float32(scaled_power)),
+                                    float(np.float32(min_value)), int(threshold_view),
+                                    self.T if tri_count is None else int(tri_count)))
 
     def dosage_to_color(self, min_value, threshold_view, tri_count=None):
         self._ck(self._L.uvrt_dosage_to_color(self._h, float(np.float32(min_value)),

@@ -83,6 +83,8 @@ struct uvrt_ctx {
     int64_t capacity = 0;
     DevBuf rays, keyrank, sorted, order, hits, hist, bin_start, export_buf;
     DevBuf recip, recip_sorted, ovf_stack;   // f64 reciprocals [3][capacity]; persistent-kernel cursor
+    bool recs_valid = false;                   // recs[0, npairs) prepared for the lamp (recs_ox, recs_oz)
+    float recs_ox = 0, recs_oz = 0;
     bool recip_valid = false;                  // recip / recip_sorted hold RN64(1/dir) of the current rays
     bool scene_force_exact = false;            // a node bound too tiny / too large for the reciprocal shortcuts
     int32_t hist_bins = 0;
@@ -355,6 +357,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->root_ref = root_ref;
     c->top_pairs = top_pairs;
     c->npairs = (int32_t)pairs.size();
+    c->recs_valid = false;
     c->have_scene = true;
     c->scene_force_exact = tiny_bound || huge_vertex;
     return UVRT_OK;
@@ -455,8 +458,16 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
         p.hist = c->hist.as<uint32_t>();
         split_bits(bits, p.bits_phi, p.bits_y, p.bits_o);
     }
+    if (!want_recip && c->npairs > 0) {   // v6: its per-launch records ride along in the same launch
+        p.prep_pairs = c->pairs.as<PairRec>();
+        p.prep_recs = c->recs.as<float4>();
+        p.prep_npairs = c->npairs;
+    }
     launch_generate(p, c->stream);
     HIP_TRY(hipGetLastError());
+    c->recs_valid = p.prep_recs != nullptr;
+    c->recs_ox = lp[0];
+    c->recs_oz = lp[2];
     if (p.keyrank) {
         launch_scan_bins(c->hist.as<uint32_t>(), c->bin_start.as<uint32_t>(), 1 << bits, c->stream);
         launch_scatter(c->rays.as<float4>(), c->keyrank.as<uint2>(), c->bin_start.as<uint32_t>(),
@@ -519,6 +530,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.lpairs = c->lpairs.p;
     p.npairs = c->npairs;
     p.recs = c->recs.p;
+    p.recs_prepared = (c->recs_valid && memcmp(&c->recs_ox, &c->ox, 4) == 0 && memcmp(&c->recs_oz, &c->oz, 4) == 0) ? 1 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -593,6 +605,21 @@ int uvrt_dosage_to_color(uvrt_ctx* c, float min_value, int32_t threshold_view, i
     if (int rc = set_device(c)) return rc;
     launch_dosage_to_color(c->dosage.as<float>(), c->color.as<float>(), min_value, threshold_view,
                            tri_count, c->stream);
+    HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+
+int uvrt_shade(uvrt_ctx* c, int32_t which, int32_t photons_per_light, float scaled_power, float min_value,
+               int32_t threshold_view, int32_t tri_count)
+{
+    if (!c || !c->have_scene || tri_count < 0 || tri_count > c->T)
+        return fail(UVRT_ERR_INVALID, "uvrt_shade: bad tri_count");
+    if (which != UVRT_MAP_SUM && which != UVRT_MAP_MAX)
+        return fail(UVRT_ERR_INVALID, "uvrt_shade: which_map must be 0 or 1");
+    if (int rc = set_device(c)) return rc;
+    const double* map = which == UVRT_MAP_SUM ? c->photon_map.as<double>() : c->max_map.as<double>();
+    launch_shade(map, c->dosage.as<float>(), c->area.as<float>(), c->color.as<float>(), photons_per_light,
+                 scaled_power, min_value, threshold_view, tri_count, c->stream);
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -730,6 +757,7 @@ int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
                                (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->recip_valid = true;
+    c->recs_valid = false;
     c->last_n = n;
     c->last_first = 0;
     c->last_sorted = false;

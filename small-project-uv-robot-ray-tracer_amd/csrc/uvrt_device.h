@@ -43,6 +43,22 @@ struct SceneDev {
     int32_t tri_count;
 };
 
+// One per-launch node-pair record of extend v6 (layout: uvrt_extend6.hip): the lamp's x / z
+// subtracted from the x / z bounds (the single f32 subtraction of extend.cl:31,35), one axis of one
+// child per register pair, leaf references re-based to record indices.
+__device__ __forceinline__ void prepare_record6(const PairRec* __restrict__ pairs, float4* __restrict__ recs,
+                                                float ox, float oz, int32_t npairs, int i)
+{
+    const PairRec pr = pairs[i];
+    uint32_t r0 = __float_as_uint(pr.c0min_ref0.w), r1 = __float_as_uint(pr.c0max_ref1.w);
+    if (r0 >= REF_LEAF_BIT) r0 += (uint32_t)npairs;
+    if (r1 >= REF_LEAF_BIT) r1 += (uint32_t)npairs;
+    recs[i * 4 + 0] = make_float4(pr.c0min_ref0.x - ox, pr.c0max_ref1.x - ox, pr.c0min_ref0.z - oz, pr.c0max_ref1.z - oz);
+    recs[i * 4 + 1] = make_float4(pr.c1min.x - ox, pr.c1max.x - ox, pr.c1min.z - oz, pr.c1max.z - oz);
+    recs[i * 4 + 2] = make_float4(pr.c0min_ref0.y, pr.c0max_ref1.y, pr.c1min.y, pr.c1max.y);
+    recs[i * 4 + 3] = make_float4(__uint_as_float(r0), __uint_as_float(r1), 0.f, 0.f);
+}
+
 struct GenParams {
     float4* rays;          // [n] gid order: dir.xyz, orig.y
     double* recip;         // [3][capacity] RN64(1/dir) per component, gid order (nullptr: skip)
@@ -56,6 +72,11 @@ struct GenParams {
     uint32_t seed_prev;    // SEED_{k-1}: read by work-item 0
     uint32_t seed_next;    // SEED_k: read by everybody else
     int32_t bits_phi, bits_y, bits_o;
+    // extend v6's per-launch records, written by extra workgroups of the same launch (or nullptr)
+    const PairRec* prep_pairs;
+    float4* prep_recs;
+    int32_t prep_npairs;
+    uint32_t ray_blocks;   // workgroups [0, ray_blocks) generate rays, the rest prepare records
 };
 
 struct ExtendParams {
@@ -84,6 +105,7 @@ struct ExtendParams {
     int32_t npairs;
     void* recs;              // extend v6: [npairs] per-launch pair records + [T] leaf records, 64 B each
     int32_t refill_min;      // extend v6: idle lanes that trigger a refill (16)
+    int32_t recs_prepared;   // extend v6: recs[0, npairs) already hold this launch's records (k_generate)
     uint32_t root_ref6;      // root reference in v6's record numbering (set by launch_extend6)
 };
 
@@ -110,6 +132,8 @@ void launch_fold_counts(int32_t* counts, int32_t replicas, int64_t stride, int32
 void launch_compute_dosage(const double* map, float* dosage, const float* area,
                            int32_t photons_per_light, float scaled_power, int32_t T,
                            hipStream_t s);
+void launch_shade(const double* map, float* dosage, const float* area, float* color, int32_t photons_per_light,
+                  float scaled_power, float min_value, int32_t threshold_view, int32_t T, hipStream_t s);
 void launch_dosage_to_color(const float* dosage, float* color, float min_value,
                             int32_t threshold_view, int32_t T, hipStream_t s);
 void launch_prepare_scene(const float4* tris64, const uint32_t* tri_idx, LeafTri* ltris,

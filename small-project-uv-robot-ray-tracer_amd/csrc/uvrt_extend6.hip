@@ -356,14 +356,7 @@ __global__ __launch_bounds__(256) void k_prepare_launch6(const PairRec* __restri
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= npairs) return;
-    const PairRec pr = pairs[i];
-    uint32_t r0 = __float_as_uint(pr.c0min_ref0.w), r1 = __float_as_uint(pr.c0max_ref1.w);
-    if (r0 >= REF_LEAF_BIT) r0 += (uint32_t)npairs;
-    if (r1 >= REF_LEAF_BIT) r1 += (uint32_t)npairs;
-    recs[i * 4 + 0] = make_float4(pr.c0min_ref0.x - ox, pr.c0max_ref1.x - ox, pr.c0min_ref0.z - oz, pr.c0max_ref1.z - oz);
-    recs[i * 4 + 1] = make_float4(pr.c1min.x - ox, pr.c1max.x - ox, pr.c1min.z - oz, pr.c1max.z - oz);
-    recs[i * 4 + 2] = make_float4(pr.c0min_ref0.y, pr.c0max_ref1.y, pr.c1min.y, pr.c1max.y);
-    recs[i * 4 + 3] = make_float4(__uint_as_float(r0), __uint_as_float(r1), 0.f, 0.f);
+    prepare_record6(pairs, recs, ox, oz, npairs, i);
 }
 
 // Leaf-triangle records recs[P, P + T) (64 bytes each), once per scene
@@ -401,7 +394,7 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
     if ((uint64_t)grid * 256 * (MAXS6 - PS6) > p.ovf_capacity) return false;
     p.root_ref6 = (p.scene.root_ref >= REF_LEAF_BIT && p.scene.root_ref != REF_DONE)
                       ? p.scene.root_ref + (uint32_t)p.npairs : p.scene.root_ref;
-    if (p.npairs > 0)
+    if (p.npairs > 0 && !p.recs_prepared)
         hipLaunchKernelGGL(k_prepare_launch6, dim3((unsigned)((p.npairs + 255) / 256)), dim3(256), 0, s,
                            p.scene.pairs, (float4*)p.recs, p.ox, p.oz, p.npairs);
 #define UVRT_L6(LP, TOP)                                                                             \

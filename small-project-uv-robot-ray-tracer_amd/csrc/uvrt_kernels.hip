@@ -57,6 +57,11 @@ __device__ __forceinline__ uint32_t coherence_key(uint32_t qphi, uint32_t qy, ui
 
 __global__ __launch_bounds__(256) void k_generate(GenParams p)
 {
+    if (blockIdx.x >= p.ray_blocks) {   // extra workgroups: extend v6's per-launch node-pair records
+        const int j = (int)(blockIdx.x - p.ray_blocks) * 256 + threadIdx.x;
+        if (j < p.prep_npairs) prepare_record6(p.prep_pairs, p.prep_recs, p.lx, p.lz, p.prep_npairs, j);
+        return;
+    }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const int64_t gid = p.first_gid + i;
@@ -956,6 +961,30 @@ __global__ __launch_bounds__(256) void k_dosage_to_color(const float* __restrict
     c[6] = r; c[7] = g; c[8] = b;
 }
 
+// computeDosage + dosageToColor in one pass (RayTracer::Shade always runs them back to back,
+// raytracer.cpp:93-120); same operations, the dose still goes through its f32 store
+__global__ __launch_bounds__(256) void k_shade(const double* __restrict__ map, float* __restrict__ dosage,
+                                               const float* __restrict__ area, float* __restrict__ color,
+                                               int32_t photons_per_light, float scaled_power,
+                                               float min_value, int32_t threshold_view, int32_t T)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    const double num = (double)scaled_power * map[i];                   // shade.cl:39
+    const float den = area[i] * (float)photons_per_light;
+    const float dose = (float)(num / (double)den);
+    dosage[i] = dose;
+    const float maxValue = min_value * 2;                               // shade.cl:47-50
+    const float norm = dose / maxValue;
+    float r, g, b;
+    if (threshold_view && norm < 0.5f) { r = 0.0f; g = 0.0f; b = norm * 2.0f; }
+    else heatmap(norm, r, g, b);
+    float* c = color + (int64_t)i * 9;
+    c[0] = r; c[1] = g; c[2] = b;
+    c[3] = r; c[4] = g; c[5] = b;
+    c[6] = r; c[7] = g; c[8] = b;
+}
+
 // Test hook: the reference's 32-byte Ray records (cl/tools.cl:8-14) in gid order.
 __global__ __launch_bounds__(256) void k_export_rays(const float4* __restrict__ rays,
                                                      const uint2* __restrict__ hits,
@@ -975,10 +1004,13 @@ __global__ __launch_bounds__(256) void k_export_rays(const float4* __restrict__ 
 
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_generate(const GenParams& p, hipStream_t s)
+void launch_generate(const GenParams& p0, hipStream_t s)
 {
-    if (p.n <= 0) return;
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(p.n, 256)), dim3(256), 0, s, p);
+    GenParams p = p0;
+    p.ray_blocks = p.n > 0 ? blocks_for(p.n, 256) : 0u;
+    const unsigned prep_blocks = p.prep_recs ? blocks_for(p.prep_npairs, 256) : 0u;
+    if (p.ray_blocks + prep_blocks == 0) return;
+    hipLaunchKernelGGL(k_generate, dim3(p.ray_blocks + prep_blocks), dim3(256), 0, s, p);
 }
 
 void launch_fill_recip(const float4* rays, double* recip, int64_t recip_stride, int64_t n, hipStream_t s)
@@ -1079,6 +1111,14 @@ void launch_compute_dosage(const double* map, float* dosage, const float* area,
     if (T <= 0) return;
     hipLaunchKernelGGL(k_compute_dosage, dim3(blocks_for(T, 256)), dim3(256), 0, s, map, dosage,
                        area, photons_per_light, scaled_power, T);
+}
+
+void launch_shade(const double* map, float* dosage, const float* area, float* color, int32_t photons_per_light,
+                  float scaled_power, float min_value, int32_t threshold_view, int32_t T, hipStream_t s)
+{
+    if (T <= 0) return;
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(T, 256)), dim3(256), 0, s, map, dosage, area, color,
+                       photons_per_light, scaled_power, min_value, threshold_view, T);
 }
 
 void launch_dosage_to_color(const float* dosage, float* color, float min_value,

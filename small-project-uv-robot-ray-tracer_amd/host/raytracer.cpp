@@ -186,14 +186,12 @@ void RayTracer::Shade()                                      // raytracer.cpp:93
 {
     if (viewMode == maxpower) {
         // only the photons of one iteration; x100: W/m^2 -> microW/cm^2
-        check(uvrt_compute_dosage(ctx, UVRT_MAP_MAX, photonsPerLight, lightIntensity * 100, mesh->triangleCount),
-              "computeDosage");
-        check(uvrt_dosage_to_color(ctx, minPower, thresholdView, mesh->triangleCount), "dosageToColor");
+        check(uvrt_shade(ctx, UVRT_MAP_MAX, photonsPerLight, lightIntensity * 100, minPower, thresholdView,
+                         mesh->triangleCount), "computeDosage + dosageToColor");
     } else {
         // x0.1: J/m^2 -> mJ/cm^2
-        check(uvrt_compute_dosage(ctx, UVRT_MAP_SUM, photonMapSize / (int)lightPositions.size(),
-                                  lightIntensity * 0.1f, mesh->triangleCount), "computeDosage");
-        check(uvrt_dosage_to_color(ctx, minDosage, thresholdView, mesh->triangleCount), "dosageToColor");
+        check(uvrt_shade(ctx, UVRT_MAP_SUM, photonMapSize / (int)lightPositions.size(), lightIntensity * 0.1f,
+                         minDosage, thresholdView, mesh->triangleCount), "computeDosage + dosageToColor");
     }
 }
 

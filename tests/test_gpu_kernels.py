@@ -145,6 +145,21 @@ def test_full_iteration_two_lamps_matches_survey_golden(ctx, orc, oscene, oroute
     ctx.dosage_to_color(oroute["minPower"], True)
     ctx.sync()
     assert np.array_equal(bits(ctx.read_color()), bits(orc.dosage_to_color(mp, oroute["minPower"], True)))
+    # the fused Shade launch (uvrt_shade) = computeDosage followed by dosageToColor, same bits
+    for which, n_ppl, power, min_value, thr, want in (
+            (0, size // len(lamps), scaled, oroute["minDosage"], False, ref_dose),
+            (1, ppl, np.float32(np.float32(oroute["lightIntensity"]) * np.float32(100)), oroute["minPower"], True, mp)):
+        ctx.reset(True)            # clears the colour buffer; the maps are rebuilt below
+        ctx.seed = 0
+        for lamp in lamps:
+            ctx.generate(comp.lamp_world_pos(lamp), oroute["lightLength"], 0, ppl)
+            ctx.extend(ppl)
+            ctx.accumulate(lamp[2])
+        ctx.shade(which, n_ppl, power, min_value, thr)
+        ctx.sync()
+        got = ctx.read_dosage()
+        assert np.array_equal(bits(got), bits(want))
+        assert np.array_equal(bits(ctx.read_color()), bits(orc.dosage_to_color(want, min_value, thr)))
 
 
 def pkg_map_sum():
