@@ -124,6 +124,12 @@ int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
  * run live on the same GPU, bit for bit.  Everything else (slab test, traversal, deposit) is
  * common to both flavours. */
 int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
+/* Renumber the node-pair records of the default extend kernel: record i (breadth-first index of the
+ * inner node, as uvrt_set_scene lays them out) moves to perm[i]; the first 127 records of the new
+ * numbering are served from LDS.  Results do not depend on it.  NULL restores the breadth-first
+ * order.  Reset by uvrt_set_scene. */
+int uvrt_set_record_perm(uvrt_ctx* ctx, const uint32_t* perm, int32_t n);
+
 /* extend kernel variant (developer / A-B knob; every variant is bit-exact): 0 = default (extend v6);
  * 1-99 = the v1-v4 kernels (90 = the v4 default of earlier builds); 200-399 = v5; 400-899 = v6
  * with explicit leaf period / top cache / grid / refill settings; +100 on 0-99, 300-399 and 500-599

@@ -47,6 +47,7 @@ SYMBOLS = [
     ("uvrt_set_record_hits", C.c_int, [_vp, _i32]),
     ("uvrt_set_flavour", C.c_int, [_vp, _i32]),
     ("uvrt_set_variant", C.c_int, [_vp, _i32]),
+    ("uvrt_set_record_perm", C.c_int, [_vp, _vp, _i32]),
     ("uvrt_read_rays", C.c_int, [_vp, _vp, _i64, _i64]),
     ("uvrt_write_rays", C.c_int, [_vp, _vp, _i64]),
     ("uvrt_read_counts", C.c_int, [_vp, _vp, _i32, _i32]),
@@ -217,6 +218,13 @@ class Ctx:
 
     def set_flavour(self, f):
         self._ck(self._L.uvrt_set_flavour(self._h, int(f)))
+
+    def set_record_perm(self, perm):
+        if perm is None:
+            self._ck(self._L.uvrt_set_record_perm(self._h, None, 0))
+            return
+        perm = np.ascontiguousarray(perm, dtype=np.uint32)
+        self._ck(self._L.uvrt_set_record_perm(self._h, perm.ctypes.data, int(perm.size)))
 
     def set_variant(self, v):
         self._ck(self._L.uvrt_set_variant(self._h, int(v)))

@@ -68,7 +68,9 @@ struct uvrt_ctx {
 
     // scene
     int32_t T = 0;
-    DevBuf pairs, lpairs, recs, ltris, leaf_count, area;
+    DevBuf pairs, lpairs, recs, perm, ltris, leaf_count, area;
+    bool have_perm = false;      // extend v6 record renumbering (uvrt_set_record_perm)
+    uint32_t perm_root = 0;
     int32_t npairs = 0;
     uint32_t root_ref = REF_DONE;
     uint32_t top_pairs = 0;      // inner nodes of the first 7 tree levels (breadth-first prefix of `pairs`)
@@ -212,7 +214,7 @@ void uvrt_destroy(uvrt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->pairs, &c->lpairs, &c->recs, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
+    for (DevBuf* b : {&c->pairs, &c->lpairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
                       &c->recip, &c->recip_sorted, &c->ovf_stack, &c->error_flag})
@@ -358,6 +360,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->top_pairs = top_pairs;
     c->npairs = (int32_t)pairs.size();
     c->recs_valid = false;
+    c->have_perm = false;
     c->have_scene = true;
     c->scene_force_exact = tiny_bound || huge_vertex;
     return UVRT_OK;
@@ -461,6 +464,7 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (!want_recip && c->npairs > 0) {   // v6: its per-launch records ride along in the same launch
         p.prep_pairs = c->pairs.as<PairRec>();
         p.prep_recs = c->recs.as<float4>();
+        p.prep_perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
         p.prep_npairs = c->npairs;
     }
     launch_generate(p, c->stream);
@@ -530,6 +534,8 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.lpairs = c->lpairs.p;
     p.npairs = c->npairs;
     p.recs = c->recs.p;
+    p.perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
+    p.perm_root = c->perm_root;
     p.recs_prepared = (c->recs_valid && memcmp(&c->recs_ox, &c->ox, 4) == 0 && memcmp(&c->recs_oz, &c->oz, 4) == 0) ? 1 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
@@ -606,6 +612,28 @@ int uvrt_dosage_to_color(uvrt_ctx* c, float min_value, int32_t threshold_view, i
     launch_dosage_to_color(c->dosage.as<float>(), c->color.as<float>(), min_value, threshold_view,
                            tri_count, c->stream);
     HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+
+int uvrt_set_record_perm(uvrt_ctx* c, const uint32_t* perm, int32_t n)
+{
+    if (!c || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_set_record_perm: no scene");
+    if (int rc = set_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->recs_valid = false;
+    if (!perm) { c->have_perm = false; return UVRT_OK; }
+    if (n != c->npairs) return fail(UVRT_ERR_INVALID, "uvrt_set_record_perm: %d entries, the scene has %d inner nodes", n, c->npairs);
+    std::vector<uint8_t> seen((size_t)n, 0);
+    for (int32_t i = 0; i < n; ++i) {
+        if (perm[i] >= (uint32_t)n || seen[perm[i]]) return fail(UVRT_ERR_INVALID, "uvrt_set_record_perm: not a permutation");
+        seen[perm[i]] = 1;
+    }
+    if (n == 0) { c->have_perm = false; return UVRT_OK; }
+    if (int rc = c->perm.ensure((size_t)n * 4, false, c->stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->perm.p, perm, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->perm_root = perm[0];
+    c->have_perm = true;
     return UVRT_OK;
 }
 

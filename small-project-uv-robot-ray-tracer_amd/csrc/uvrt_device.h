@@ -46,13 +46,18 @@ struct SceneDev {
 // One per-launch node-pair record of extend v6 (layout: uvrt_extend6.hip): the lamp's x / z
 // subtracted from the x / z bounds (the single f32 subtraction of extend.cl:31,35), one axis of one
 // child per register pair, leaf references re-based to record indices.
+// `perm` (or nullptr = identity) renumbers the pair records: record i is written at perm[i] and the
+// inner references are translated, so that the records the lamp's rays visit most form the prefix
+// that the kernel serves from LDS.
 __device__ __forceinline__ void prepare_record6(const PairRec* __restrict__ pairs, float4* __restrict__ recs,
-                                                float ox, float oz, int32_t npairs, int i)
+                                                float ox, float oz, int32_t npairs, int src,
+                                                const uint32_t* __restrict__ perm)
 {
-    const PairRec pr = pairs[i];
+    const PairRec pr = pairs[src];
     uint32_t r0 = __float_as_uint(pr.c0min_ref0.w), r1 = __float_as_uint(pr.c0max_ref1.w);
-    if (r0 >= REF_LEAF_BIT) r0 += (uint32_t)npairs;
-    if (r1 >= REF_LEAF_BIT) r1 += (uint32_t)npairs;
+    if (r0 >= REF_LEAF_BIT) r0 += (uint32_t)npairs; else if (perm) r0 = perm[r0];
+    if (r1 >= REF_LEAF_BIT) r1 += (uint32_t)npairs; else if (perm) r1 = perm[r1];
+    const int i = perm ? (int)perm[src] : src;
     recs[i * 4 + 0] = make_float4(pr.c0min_ref0.x - ox, pr.c0max_ref1.x - ox, pr.c0min_ref0.z - oz, pr.c0max_ref1.z - oz);
     recs[i * 4 + 1] = make_float4(pr.c1min.x - ox, pr.c1max.x - ox, pr.c1min.z - oz, pr.c1max.z - oz);
     recs[i * 4 + 2] = make_float4(pr.c0min_ref0.y, pr.c0max_ref1.y, pr.c1min.y, pr.c1max.y);
@@ -75,6 +80,7 @@ struct GenParams {
     // extend v6's per-launch records, written by extra workgroups of the same launch (or nullptr)
     const PairRec* prep_pairs;
     float4* prep_recs;
+    const uint32_t* prep_perm;
     int32_t prep_npairs;
     uint32_t ray_blocks;   // workgroups [0, ray_blocks) generate rays, the rest prepare records
 };
@@ -105,6 +111,8 @@ struct ExtendParams {
     int32_t npairs;
     void* recs;              // extend v6: [npairs] per-launch pair records + [T] leaf records, 64 B each
     int32_t refill_min;      // extend v6: idle lanes that trigger a refill (16)
+    const uint32_t* perm;    // extend v6: record renumbering (nullptr = identity), see prepare_record6
+    uint32_t perm_root;      // perm[0]
     int32_t recs_prepared;   // extend v6: recs[0, npairs) already hold this launch's records (k_generate)
     uint32_t root_ref6;      // root reference in v6's record numbering (set by launch_extend6)
 };

@@ -160,7 +160,6 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
     const bool is_inner = cur < REF_LEAF_BIT;
     const bool is_leaf = (cur >= REF_LEAF_BIT) & (cur != REF_DONE) & leaf_trip;
     const uint32_t idx = cur & REF_FIRST_MASK;          // record index (inner indices are < 2^27 too)
-    const bool in_top = TOP && cur < top_pairs;
     // ONE asm block fetches the 64-byte record of every stepping lane -- from the LDS top-of-tree
     // cache or from global memory, chosen by exec masks -- and the lane's stack top, so that both
     // sources write the same registers (hipcc otherwise merges the two branches with v_mov chains).
@@ -169,10 +168,15 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
     // stack entry sp - 1 of this lane (lanes with sp == 0 are masked off); entry sp is 1024 bytes on
     const uint32_t sa = stack_base + ((uint32_t)L.sp << 10);
     {
-        const bool go = is_inner | is_leaf;
-        const unsigned long long m_top = __ballot(in_top & go);
-        const unsigned long long m_glob = __ballot(go & !in_top);
-        const unsigned long long m_stk = __ballot(go & (L.sp > 0));
+        // lane masks from single comparisons, combined as 64-bit integers (SALU): a ballot of a
+        // compound condition would go through a v_cndmask / v_cmp pair
+        const unsigned long long m_in = __builtin_amdgcn_ballot_w64(cur < REF_LEAF_BIT);
+        const unsigned long long m_act = __builtin_amdgcn_ballot_w64(cur != REF_DONE);
+        const unsigned long long m_top = TOP ? __builtin_amdgcn_ballot_w64(cur < top_pairs) : 0ull;
+        const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(L.sp > 0);
+        const unsigned long long m_go = m_in | (leaf_trip ? (m_act & ~m_in) : 0ull);
+        const unsigned long long m_glob = m_go & ~m_top;
+        const unsigned long long m_stk = m_go & m_sp;
         // LDS copy of record r at byte 80 r: the 16 padding bytes spread the lanes of a ds_read_b128
         // over sixteen 4-bank windows (20 r mod 64) instead of four
         const uint32_t a0 = (uint32_t)(uintptr_t)s_top + cur * TOP6_STRIDE;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     uint32_t trip = 0;
 
     for (;;) {
-        const unsigned long long idle_mask = __ballot(L.cur == REF_DONE);
+        const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(L.cur == REF_DONE);
         const int nidle = __popcll(idle_mask);
         if (cursor < chunk_end && nidle >= p.refill_min) {
             bool spec = false;
@@ -323,16 +327,16 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                 }
             }
             cursor += (uint32_t)nidle;
-            special_mask = (special_mask & ~idle_mask) | __ballot(spec);
+            special_mask = (special_mask & ~idle_mask) | __builtin_amdgcn_ballot_w64(spec);
         }
-        const unsigned long long act = __ballot(L.cur != REF_DONE);
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(L.cur != REF_DONE);
         if (act == 0) {
             if (cursor >= chunk_end) break;
             continue;
         }
         bool leaf_trip = true;
         if (LEAFP > 1) {
-            leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __ballot(L.cur < REF_LEAF_BIT) == 0;
+            leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __builtin_amdgcn_ballot_w64(L.cur < REF_LEAF_BIT) == 0;
             ++trip;
         }
         step6<TOP>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0);
@@ -352,11 +356,11 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 //   w2 = {c0 miny, c0 maxy, c1 miny, c1 maxy} (raw), w3 = {ref0, ref1, 0, 0}
 __global__ __launch_bounds__(256) void k_prepare_launch6(const PairRec* __restrict__ pairs,
                                                          float4* __restrict__ recs, float ox, float oz,
-                                                         int32_t npairs)
+                                                         int32_t npairs, const uint32_t* __restrict__ perm)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= npairs) return;
-    prepare_record6(pairs, recs, ox, oz, npairs, i);
+    prepare_record6(pairs, recs, ox, oz, npairs, i, perm);
 }
 
 // Leaf-triangle records recs[P, P + T) (64 bytes each), once per scene
@@ -393,10 +397,12 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
     p.chunk = (uint32_t)((((uint64_t)p.n + waves - 1) / waves + 63) / 64 * 64);
     if ((uint64_t)grid * 256 * (MAXS6 - PS6) > p.ovf_capacity) return false;
     p.root_ref6 = (p.scene.root_ref >= REF_LEAF_BIT && p.scene.root_ref != REF_DONE)
-                      ? p.scene.root_ref + (uint32_t)p.npairs : p.scene.root_ref;
+                      ? p.scene.root_ref + (uint32_t)p.npairs
+                      : (p.perm && p.scene.root_ref != REF_DONE ? p.perm_root : p.scene.root_ref);
+    if (p.perm) p.top_pairs = (uint32_t)p.npairs;   // the hot prefix: as many records as the cache holds
     if (p.npairs > 0 && !p.recs_prepared)
         hipLaunchKernelGGL(k_prepare_launch6, dim3((unsigned)((p.npairs + 255) / 256)), dim3(256), 0, s,
-                           p.scene.pairs, (float4*)p.recs, p.ox, p.oz, p.npairs);
+                           p.scene.pairs, (float4*)p.recs, p.ox, p.oz, p.npairs, p.perm);
 #define UVRT_L6(LP, TOP)                                                                             \
     do {                                                                                             \
         if (p.hits) hipLaunchKernelGGL((k_extend6<LP, true, TOP>), dim3(grid), dim3(256), 0, s, p);    \

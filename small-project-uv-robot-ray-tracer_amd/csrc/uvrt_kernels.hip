@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_generate(GenParams p)
 {
     if (blockIdx.x >= p.ray_blocks) {   // extra workgroups: extend v6's per-launch node-pair records
         const int j = (int)(blockIdx.x - p.ray_blocks) * 256 + threadIdx.x;
-        if (j < p.prep_npairs) prepare_record6(p.prep_pairs, p.prep_recs, p.lx, p.lz, p.prep_npairs, j);
+        if (j < p.prep_npairs) prepare_record6(p.prep_pairs, p.prep_recs, p.lx, p.lz, p.prep_npairs, j, p.prep_perm);
         return;
     }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
