@@ -130,6 +130,14 @@ int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
  * order.  Reset by uvrt_set_scene. */
 int uvrt_set_record_perm(uvrt_ctx* ctx, const uint32_t* perm, int32_t n);
 
+/* Launch pipelining (on by default): consecutive launches (generate, extend, accumulate and the Shade
+ * that follows) alternate between the context's stream and an internal second stream with their own
+ * ray / count buffers, so the next launch starts in the wave slots the previous one frees while its
+ * last rays finish.  The per-triangle maps are still updated in launch order and every other entry
+ * point first orders the context's stream after all outstanding work, so callers see the in-order
+ * behaviour of the reference's single command queue.  0 = everything on the one stream. */
+int uvrt_set_pipeline(uvrt_ctx* ctx, int32_t on);
+
 /* extend kernel variant (developer / A-B knob; every variant is bit-exact): 0 = default (extend v6);
  * 1-99 = the v1-v4 kernels (90 = the v4 default of earlier builds); 200-399 = v5; 400-899 = v6
  * with explicit leaf period / top cache / grid / refill settings; +100 on 0-99, 300-399 and 500-599

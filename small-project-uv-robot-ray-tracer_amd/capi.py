@@ -47,6 +47,7 @@ SYMBOLS = [
     ("uvrt_set_record_hits", C.c_int, [_vp, _i32]),
     ("uvrt_set_flavour", C.c_int, [_vp, _i32]),
     ("uvrt_set_variant", C.c_int, [_vp, _i32]),
+    ("uvrt_set_pipeline", C.c_int, [_vp, _i32]),
     ("uvrt_set_record_perm", C.c_int, [_vp, _vp, _i32]),
     ("uvrt_read_rays", C.c_int, [_vp, _vp, _i64, _i64]),
     ("uvrt_write_rays", C.c_int, [_vp, _vp, _i64]),
@@ -225,6 +226,9 @@ class Ctx:
             return
         perm = np.ascontiguousarray(perm, dtype=np.uint32)
         self._ck(self._L.uvrt_set_record_perm(self._h, perm.ctypes.data, int(perm.size)))
+
+    def set_pipeline(self, on):
+        self._ck(self._L.uvrt_set_pipeline(self._h, int(bool(on))))
 
     def set_variant(self, v):
         self._ck(self._L.uvrt_set_variant(self._h, int(v)))

@@ -96,6 +96,22 @@ struct uvrt_ctx {
     bool last_extended = false;
     float ox = 0, oz = 0;
 
+    // Launch lanes: consecutive launches (generate -> extend -> accumulate ->
+    // shade) alternate between the context's stream and an internal side stream, each with its own
+    // ray, record, count and overflow-stack buffers, so that the next launch fills the wave slots the
+    // draining launch frees.  The per-triangle maps are updated in launch order (event waits).
+    bool pipeline = true;             // uvrt_set_pipeline
+    bool ext_touch = false;           // a device pointer was handed out since the last fence
+    int lane = 0;                     // lane of the current launch (uvrt_generate selects it)
+    hipStream_t side = nullptr;
+    bool side_used = false;           // the side stream holds work the main stream is not ordered after
+    hipEvent_t ev_fence = nullptr;    // on the main stream, after the last context-wide operation
+    hipEvent_t ev_tail = nullptr;     // scratch: tail of "the other" stream
+    uint64_t fence_seq = 0, side_seen_fence = 0;
+    DevBuf rays2, recs2, counts2, ovf2;
+    bool recs_valid2 = false;
+    float recs_ox2 = 0, recs_oz2 = 0;
+
     // generate.cl:6 program-scope SEED
     uint32_t seed = 0;
 
@@ -119,6 +135,53 @@ int set_device(uvrt_ctx* c)
     HIP_TRY(hipSetDevice(c->device));
     return UVRT_OK;
 }
+
+// ---- launch lanes ----
+// the main stream becomes ordered after everything the side stream holds
+int join_all(uvrt_ctx* c)
+{
+    if (!c->side_used) return UVRT_OK;
+    HIP_TRY(hipEventRecord(c->ev_tail, c->side));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+    c->side_used = false;
+    return UVRT_OK;
+}
+// a context-wide operation has been enqueued on the main stream: later side-stream work waits for it
+int mark_fence(uvrt_ctx* c)
+{
+    HIP_TRY(hipEventRecord(c->ev_fence, c->stream));
+    ++c->fence_seq;
+    return UVRT_OK;
+}
+// stream of the current lane; the side stream first catches up with the last context-wide operation
+int lane_stream(uvrt_ctx* c, hipStream_t* out)
+{
+    if (c->lane == 0) { *out = c->stream; return UVRT_OK; }
+    if (c->ext_touch) {   // external work (e.g. an RCCL reduction on the maps) sits on the main stream
+        c->ext_touch = false;
+        if (int rc = mark_fence(c)) return rc;
+    }
+    if (c->fence_seq != c->side_seen_fence) {
+        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fence, 0));
+        c->side_seen_fence = c->fence_seq;
+    }
+    c->side_used = true;
+    *out = c->side;
+    return UVRT_OK;
+}
+// the current lane's stream becomes ordered after everything the other lane's stream holds
+int order_after_other(uvrt_ctx* c)
+{
+    if (c->lane == 0) return join_all(c);
+    HIP_TRY(hipEventRecord(c->ev_tail, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_tail, 0));
+    c->side_used = true;
+    return UVRT_OK;
+}
+DevBuf& lane_rays(uvrt_ctx* c) { return c->lane ? c->rays2 : c->rays; }
+DevBuf& lane_recs(uvrt_ctx* c) { return c->lane ? c->recs2 : c->recs; }
+DevBuf& lane_counts(uvrt_ctx* c) { return c->lane ? c->counts2 : c->counts; }
+DevBuf& lane_ovf(uvrt_ctx* c) { return c->lane ? c->ovf2 : c->ovf_stack; }
 
 // work-item 0's RNG walk of cl/generate.cl:13-39 on the host (strict f32/f64, same order)
 uint32_t host_wang_hash(uint32_t s)
@@ -201,6 +264,10 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     HIP_TRY(hipSetDevice(device_id));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    if (const char* e = getenv("UVRT_PIPELINE")) c->pipeline = atoi(e) != 0;   // developer knob
     int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
     if (!rc) rc = c->ovf_stack.ensure((size_t)OVF_MAX_ENTRIES * sizeof(uint32_t), false, c->stream);
@@ -214,6 +281,11 @@ void uvrt_destroy(uvrt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    for (DevBuf* b : {&c->rays2, &c->recs2, &c->counts2, &c->ovf2}) b->release();
+    if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->side) (void)hipStreamDestroy(c->side);
     for (DevBuf* b : {&c->pairs, &c->lpairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
@@ -228,8 +300,10 @@ int uvrt_set_stream(uvrt_ctx* c, void* hip_stream)
 {
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
     if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->lane = 0;
     return UVRT_OK;
 }
 
@@ -312,19 +386,22 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     if (err) return fail(UVRT_ERR_BVH, "uvrt_set_scene: malformed BVH (code %d)", err);
     if (pairs.size() >= (size_t)REF_LEAF_BIT) return fail(UVRT_ERR_BVH, "uvrt_set_scene: too many inner nodes");
 
+    if (int rcj = join_all(c)) return rcj;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->lane = 0;
     const bool resized = (T != c->T);
     int rc;
     if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
     if ((rc = c->lpairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
     if ((rc = c->recs.ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
+    if ((rc = c->recs2.ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
     // + 16 bytes: the merged record fetch of the traversal reads 64 bytes at every leaf record
     if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri) + 16, true, c->stream))) return rc;
     if ((rc = c->leaf_count.ensure((size_t)T * 4, false, c->stream))) return rc;
     if ((rc = c->area.ensure((size_t)T * 4, false, c->stream))) return rc;
     if (resized || !c->photon_map.p) {
         // raytracer.cpp:32-37 (the reference leaves them uninitialised until reset; zero here)
-        for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->dosage, &c->color}) b->release();
+        for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->counts2, &c->dosage, &c->color}) b->release();
         if ((rc = c->photon_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         if ((rc = c->max_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         // up to 64 deposit replicas, at most 64 MiB in total
@@ -332,6 +409,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         while (R > 1 && (size_t)R * (size_t)T * 4 > ((size_t)64 << 20)) R >>= 1;
         c->replicas = R;
         if ((rc = c->counts.ensure((size_t)R * (size_t)T * 4, true, c->stream))) return rc;
+        if ((rc = c->counts2.ensure((size_t)R * (size_t)T * 4, true, c->stream))) return rc;
         if ((rc = c->dosage.ensure((size_t)T * 4, true, c->stream))) return rc;
         if ((rc = c->color.ensure((size_t)T * 36, true, c->stream))) return rc;
     }
@@ -348,6 +426,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         launch_prepare_scene(d_tris.as<float4>(), d_idx.as<uint32_t>(), c->ltris.as<LeafTri>(),
                              c->area.as<float>(), T, c->stream);
         launch_prepare_leaves6(c->ltris.as<LeafTri>(), c->recs.p, (int32_t)pairs.size(), T, c->stream);
+        launch_prepare_leaves6(c->ltris.as<LeafTri>(), c->recs2.p, (int32_t)pairs.size(), T, c->stream);
         e1 = hipGetLastError();
         e2 = hipStreamSynchronize(c->stream);
     }
@@ -360,6 +439,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->top_pairs = top_pairs;
     c->npairs = (int32_t)pairs.size();
     c->recs_valid = false;
+    c->recs_valid2 = false;
     c->have_perm = false;
     c->have_scene = true;
     c->scene_force_exact = tiny_bound || huge_vertex;
@@ -371,10 +451,13 @@ int uvrt_resize_rays(uvrt_ctx* c, int64_t photon_count)
     if (!c || photon_count < 0) return fail(UVRT_ERR_INVALID, "uvrt_resize_rays: bad argument");
     if (int rc = set_device(c)) return rc;
     if (photon_count == c->capacity && c->rays.p && (!c->record_hits || c->hits.p)) { c->last_n = -1; return UVRT_OK; }
+    if (int rcj = join_all(c)) return rcj;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->lane = 0;
     int rc;
     const size_t n = (size_t)photon_count;
     if ((rc = c->rays.ensure(n * 16, false, c->stream))) return rc;
+    if ((rc = c->rays2.ensure(n * 16, false, c->stream))) return rc;
     if ((rc = c->keyrank.ensure(n * 8, false, c->stream))) return rc;
     if ((rc = c->sorted.ensure(n * 16, false, c->stream))) return rc;
     if ((rc = c->order.ensure(n * 4, false, c->stream))) return rc;
@@ -390,10 +473,12 @@ int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
 {
     if (!c || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_reset: no scene");
     if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     launch_reset(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
                  c->replicas, c->T, c->color.as<float>(), reset_color, c->T, c->stream);
     HIP_TRY(hipGetLastError());
-    return UVRT_OK;
+    if (c->counts2.p) HIP_TRY(hipMemsetAsync(c->counts2.p, 0, c->counts2.bytes, c->stream));
+    return mark_fence(c);
 }
 
 uint32_t uvrt_seed_next(const float lp[3], float light_length, uint32_t seed_prev)
@@ -432,9 +517,21 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
 
     int bits = c->sort_bits < 0 ? auto_sort_bits(n) : c->sort_bits;
     if (bits > 20) bits = 20;
+    // launch lane: alternate between the two streams / buffer sets when nothing stands against it
+    {
+        const bool pipe_ok = c->pipeline && variant_is_v6(c) && !c->record_hits && bits == 0 && c->rays2.p;
+        if (pipe_ok) c->lane ^= 1;
+        else { if (int rc = join_all(c)) return rc; c->lane = 0; }
+        if (c->lane == 1) {
+            // 8 workgroups per CU x 256 threads x 24 overflow entries (the default kernel's grid)
+            if (int rc = c->ovf2.ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream)) return rc;
+        }
+    }
+    hipStream_t ls;
+    if (int rc = lane_stream(c, &ls)) return rc;
     GenParams p;
     memset(&p, 0, sizeof p);
-    p.rays = c->rays.as<float4>();
+    p.rays = lane_rays(c).as<float4>();
     // extend v6 derives RN32(1/dir) in the kernel; the f64 reciprocals are only written for the
     // older kernels (and made up by uvrt_extend if the variant is switched after generate)
     const bool want_recip = !variant_is_v6(c);
@@ -463,15 +560,15 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     }
     if (!want_recip && c->npairs > 0) {   // v6: its per-launch records ride along in the same launch
         p.prep_pairs = c->pairs.as<PairRec>();
-        p.prep_recs = c->recs.as<float4>();
+        p.prep_recs = lane_recs(c).as<float4>();
         p.prep_perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
         p.prep_npairs = c->npairs;
     }
-    launch_generate(p, c->stream);
+    launch_generate(p, ls);
     HIP_TRY(hipGetLastError());
-    c->recs_valid = p.prep_recs != nullptr;
-    c->recs_ox = lp[0];
-    c->recs_oz = lp[2];
+    (c->lane ? c->recs_valid2 : c->recs_valid) = p.prep_recs != nullptr;
+    (c->lane ? c->recs_ox2 : c->recs_ox) = lp[0];
+    (c->lane ? c->recs_oz2 : c->recs_oz) = lp[2];
     if (p.keyrank) {
         launch_scan_bins(c->hist.as<uint32_t>(), c->bin_start.as<uint32_t>(), 1 << bits, c->stream);
         launch_scatter(c->rays.as<float4>(), c->keyrank.as<uint2>(), c->bin_start.as<uint32_t>(),
@@ -507,7 +604,9 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.scene.leaf_count = c->leaf_count.as<uint32_t>();
     p.scene.root_ref = c->root_ref;
     p.scene.tri_count = c->T;
-    p.rays = c->last_sorted ? c->sorted.as<float4>() : c->rays.as<float4>();
+    hipStream_t ls;
+    if (int rc = lane_stream(c, &ls)) return rc;
+    p.rays = c->last_sorted ? c->sorted.as<float4>() : lane_rays(c).as<float4>();
     p.recip = c->last_sorted ? c->recip_sorted.as<double>() : c->recip.as<double>();
     p.recip_stride = c->capacity;
     {
@@ -519,12 +618,12 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     }
     p.order = c->last_sorted ? c->order.as<uint32_t>() : nullptr;
     p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
-    p.ovf_stack = c->ovf_stack.as<uint32_t>();
-    p.ovf_capacity = c->ovf_stack.bytes / sizeof(uint32_t);
+    p.ovf_stack = lane_ovf(c).as<uint32_t>();
+    p.ovf_capacity = lane_ovf(c).bytes / sizeof(uint32_t);
     p.num_cus = c->num_cus;
     p.flavour = c->flavour;
     p.top_pairs = c->top_pairs;
-    p.counts = c->counts.as<int32_t>();
+    p.counts = lane_counts(c).as<int32_t>();
     p.count_replicas = c->replicas;
     p.count_stride = c->T;
     p.error_flag = c->error_flag.as<uint32_t>();
@@ -533,10 +632,14 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.n = n;
     p.lpairs = c->lpairs.p;
     p.npairs = c->npairs;
-    p.recs = c->recs.p;
+    p.recs = lane_recs(c).p;
     p.perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
     p.perm_root = c->perm_root;
-    p.recs_prepared = (c->recs_valid && memcmp(&c->recs_ox, &c->ox, 4) == 0 && memcmp(&c->recs_oz, &c->oz, 4) == 0) ? 1 : 0;
+    {
+        const bool valid = c->lane ? c->recs_valid2 : c->recs_valid;
+        const float rox = c->lane ? c->recs_ox2 : c->recs_ox, roz = c->lane ? c->recs_oz2 : c->recs_oz;
+        p.recs_prepared = (valid && memcmp(&rox, &c->ox, 4) == 0 && memcmp(&roz, &c->oz, 4) == 0) ? 1 : 0;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -548,7 +651,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         e0 = c->ev_pool[c->ev_used].first;
         e1 = c->ev_pool[c->ev_used].second;
         ++c->ev_used;
-        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(hipEventRecord(e0, ls));
     }
     const bool v6 = variant_is_v6(c);
     const bool v5 = c->variant >= 200 && c->variant < 400;
@@ -562,18 +665,18 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         return fail(UVRT_ERR_INVALID, "uvrt_extend: scene too large for extend v6's record numbering");
     if (!v6 && !c->recip_valid) {
         // the rays were generated for v6: make up the f64 reciprocals the older kernels read
-        launch_fill_recip(p.rays, const_cast<double*>(p.recip), p.recip_stride, n, c->stream);
+        launch_fill_recip(p.rays, const_cast<double*>(p.recip), p.recip_stride, n, ls);
         c->recip_valid = true;
     }
     static const int per_cu5[5] = {8, 4, 6, 2, 16};
     const int g5 = (c->variant / 10) % 10;
     const int code6 = c->variant == 0 ? 2 : c->variant % 10;
-    if (v6 ? !launch_extend6(p, code6, per_cu5[g5 < 5 ? g5 : 0], c->stream)
-        : v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], c->stream)
-             : !launch_extend(p, c->variant % 100, c->stream))
+    if (v6 ? !launch_extend6(p, code6, per_cu5[g5 < 5 ? g5 : 0], ls)
+        : v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], ls)
+             : !launch_extend(p, c->variant % 100, ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
-    if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
+    if (c->timing) HIP_TRY(hipEventRecord(e1, ls));
     c->last_extended = c->record_hits;
     return UVRT_OK;
 }
@@ -583,8 +686,13 @@ int uvrt_accumulate(uvrt_ctx* c, float time_step, int32_t tri_count)
     if (!c || !c->have_scene || tri_count < 0 || tri_count > c->T)
         return fail(UVRT_ERR_INVALID, "uvrt_accumulate: bad tri_count");
     if (int rc = set_device(c)) return rc;
-    launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
-                      c->replicas, c->T, time_step, tri_count, c->stream);
+    // the maps are updated in launch order: wait for whatever the other lane has enqueued so far
+    // (its accumulate and shade), not for this lane's successor
+    if (int rc = order_after_other(c)) return rc;
+    hipStream_t ls;
+    if (int rc = lane_stream(c, &ls)) return rc;
+    launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), lane_counts(c).as<int32_t>(),
+                      c->replicas, c->T, time_step, tri_count, ls);
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -598,8 +706,10 @@ int uvrt_compute_dosage(uvrt_ctx* c, int32_t which, int32_t photons_per_light, f
         return fail(UVRT_ERR_INVALID, "uvrt_compute_dosage: which_map must be 0 or 1");
     if (int rc = set_device(c)) return rc;
     const double* map = which == UVRT_MAP_SUM ? c->photon_map.as<double>() : c->max_map.as<double>();
+    hipStream_t ls;
+    if (int rc = lane_stream(c, &ls)) return rc;
     launch_compute_dosage(map, c->dosage.as<float>(), c->area.as<float>(), photons_per_light,
-                          scaled_power, tri_count, c->stream);
+                          scaled_power, tri_count, ls);
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -609,8 +719,10 @@ int uvrt_dosage_to_color(uvrt_ctx* c, float min_value, int32_t threshold_view, i
     if (!c || !c->have_scene || tri_count < 0 || tri_count > c->T)
         return fail(UVRT_ERR_INVALID, "uvrt_dosage_to_color: bad tri_count");
     if (int rc = set_device(c)) return rc;
+    hipStream_t ls;
+    if (int rc = lane_stream(c, &ls)) return rc;
     launch_dosage_to_color(c->dosage.as<float>(), c->color.as<float>(), min_value, threshold_view,
-                           tri_count, c->stream);
+                           tri_count, ls);
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -619,8 +731,10 @@ int uvrt_set_record_perm(uvrt_ctx* c, const uint32_t* perm, int32_t n)
 {
     if (!c || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_set_record_perm: no scene");
     if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->recs_valid = false;
+    c->recs_valid2 = false;
     if (!perm) { c->have_perm = false; return UVRT_OK; }
     if (n != c->npairs) return fail(UVRT_ERR_INVALID, "uvrt_set_record_perm: %d entries, the scene has %d inner nodes", n, c->npairs);
     std::vector<uint8_t> seen((size_t)n, 0);
@@ -646,8 +760,10 @@ int uvrt_shade(uvrt_ctx* c, int32_t which, int32_t photons_per_light, float scal
         return fail(UVRT_ERR_INVALID, "uvrt_shade: which_map must be 0 or 1");
     if (int rc = set_device(c)) return rc;
     const double* map = which == UVRT_MAP_SUM ? c->photon_map.as<double>() : c->max_map.as<double>();
+    hipStream_t ls;
+    if (int rc = lane_stream(c, &ls)) return rc;
     launch_shade(map, c->dosage.as<float>(), c->area.as<float>(), c->color.as<float>(), photons_per_light,
-                 scaled_power, min_value, threshold_view, tri_count, c->stream);
+                 scaled_power, min_value, threshold_view, tri_count, ls);
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -656,6 +772,7 @@ int uvrt_sync(uvrt_ctx* c)
 {
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
     if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     uint32_t flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, c->error_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -673,6 +790,7 @@ static int read_back(uvrt_ctx* c, const DevBuf& b, size_t elem, void* out, int64
         return fail(UVRT_ERR_INVALID, "%s: range [%lld,+%lld) outside [0,%lld)", what, (long long)first,
                     (long long)count, (long long)limit);
     if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     if (count == 0) return UVRT_OK;
     HIP_TRY(hipMemcpyAsync(out, (const char*)b.p + (size_t)first * elem, (size_t)count * elem,
                            hipMemcpyDeviceToHost, c->stream));
@@ -692,9 +810,11 @@ int uvrt_read_counts(uvrt_ctx* c, int32_t* out, int32_t first, int32_t count)
 {
     if (c && c->have_scene) {
         if (int rc = set_device(c)) return rc;
-        launch_fold_counts(c->counts.as<int32_t>(), c->replicas, c->T, c->T, c->stream);
+        if (int rc = join_all(c)) return rc;
+        launch_fold_counts(lane_counts(c).as<int32_t>(), c->replicas, c->T, c->T, c->stream);
+        if (int rc = mark_fence(c)) return rc;
     }
-    return read_back(c, c ? c->counts : DevBuf(), 4, out, first, count, c ? c->T : 0, "uvrt_read_counts");
+    return read_back(c, c ? lane_counts(c) : DevBuf(), 4, out, first, count, c ? c->T : 0, "uvrt_read_counts");
 }
 int uvrt_read_photon_map(uvrt_ctx* c, int32_t which, double* out, int32_t first, int32_t count)
 {
@@ -741,6 +861,14 @@ int uvrt_set_variant(uvrt_ctx* c, int32_t variant)
     c->variant = variant;
     return UVRT_OK;
 }
+int uvrt_set_pipeline(uvrt_ctx* c, int32_t on)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
+    c->pipeline = on != 0;
+    return UVRT_OK;
+}
 int uvrt_set_timing(uvrt_ctx* c, int32_t on)
 {
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
@@ -753,10 +881,11 @@ int uvrt_read_rays(uvrt_ctx* c, void* rays32, int64_t first, int64_t count)
     if (!c || !rays32 || c->last_n < 0 || first < 0 || count < 0 || first + count > c->last_n)
         return fail(UVRT_ERR_INVALID, "uvrt_read_rays: range outside the last generate");
     if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     if (count == 0) return UVRT_OK;
     if (int rc = c->export_buf.ensure((size_t)count * 32, false, c->stream)) return rc;
     const uint2* hits = (c->last_extended && c->hits.p) ? c->hits.as<uint2>() : nullptr;
-    launch_export_rays(c->rays.as<float4>(), hits, c->export_buf.p, c->ox, c->oz, first, count, c->stream);
+    launch_export_rays(lane_rays(c).as<float4>(), hits, c->export_buf.p, c->ox, c->oz, first, count, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rays32, c->export_buf.p, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -779,6 +908,8 @@ int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
         packed[4 * i + 2] = hr[i].d[2]; packed[4 * i + 3] = hr[i].o[1];
         for (int k = 0; k < 3; ++k) rec[(size_t)k * n + i] = 1.0 / (double)hr[i].d[k];   // as k_generate does
     }
+    if (int rc = join_all(c)) return rc;
+    c->lane = 0;
     HIP_TRY(hipMemcpyAsync(c->rays.p, packed.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     for (int k = 0; k < 3; ++k)
         HIP_TRY(hipMemcpyAsync((char*)c->recip.p + (size_t)k * c->capacity * 8, rec.data() + (size_t)k * n,
@@ -798,15 +929,18 @@ int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
 int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
 {
     if (!c || !ptr || !bytes || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: bad argument");
+    // the caller is about to touch the buffers on the context's stream: order it after the side lane,
+    // and the side lane's next work after whatever the caller enqueues up to the next call
+    if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     const DevBuf* b = nullptr;
     size_t elem = 0;
     switch (which) {
         case 0: b = &c->photon_map; elem = 8; break;
         case 1: b = &c->max_map; elem = 8; break;
         case 2:
-            b = &c->counts; elem = 4;
-            if (int rc = set_device(c)) return rc;
-            launch_fold_counts(c->counts.as<int32_t>(), c->replicas, c->T, c->T, c->stream);
+            b = &lane_counts(c); elem = 4;
+            launch_fold_counts(lane_counts(c).as<int32_t>(), c->replicas, c->T, c->T, c->stream);
             break;
         case 3: b = &c->dosage; elem = 4; break;
         case 4: b = &c->color; elem = 36; break;
@@ -814,6 +948,7 @@ int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
     }
     *ptr = b->p;
     *bytes = (int64_t)((size_t)c->T * elem);
+    c->ext_touch = true;      // see lane_stream(): the next side-lane work waits for the main stream's tail
     return UVRT_OK;
 }
 
@@ -826,13 +961,14 @@ int uvrt_copy_device(uvrt_ctx* c, int32_t which, void* ext, int32_t to_ctx)
     if (int rc = set_device(c)) return rc;
     if (to_ctx) HIP_TRY(hipMemcpyAsync(p, ext, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
     else HIP_TRY(hipMemcpyAsync(ext, p, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
-    return UVRT_OK;
+    return mark_fence(c);
 }
 
 int uvrt_extend_time_ms(uvrt_ctx* c, double* ms, int64_t* launches)
 {
     if (!c || !ms || !launches) return fail(UVRT_ERR_INVALID, "null argument");
     if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     double total = 0;
     for (size_t i = 0; i < c->ev_used; ++i) {
