@@ -135,7 +135,9 @@ int uvrt_set_record_perm(uvrt_ctx* ctx, const uint32_t* perm, int32_t n);
  * ray / count buffers, so the next launch starts in the wave slots the previous one frees while its
  * last rays finish.  The per-triangle maps are still updated in launch order and every other entry
  * point first orders the context's stream after all outstanding work, so callers see the in-order
- * behaviour of the reference's single command queue.  0 = everything on the one stream. */
+ * behaviour of the reference's single command queue.  0 = everything on the one stream.  (The
+ * tempPhotonMap pointer of uvrt_device_ptr(ctx, 2, ...) alternates with the launch lane: callers
+ * that cache it across launches must switch the pipelining off.) */
 int uvrt_set_pipeline(uvrt_ctx* ctx, int32_t on);
 
 /* extend kernel variant (developer / A-B knob; every variant is bit-exact): 0 = default (extend v6);

@@ -1,0 +1,123 @@
+"""GPU: launch pipelining (include/uvrt.h uvrt_set_pipeline).  Consecutive launches alternate between
+two streams and two sets of ray / count buffers; whatever the interleaving of ABI calls, every
+result must equal the one-stream behaviour and the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg, oscene):
+    c = pkg.capi.Ctx(0)
+    c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+    yield c
+    c.close()
+
+
+def positions(orc, oscene, oroute):
+    comp = orc.Computation(oscene, oroute["lamps"], 1 << 16, oroute["lightHeight"], oroute["lightLength"],
+                           oroute["lightIntensity"])
+    return [tuple(float(x) for x in comp.lamp_world_pos(l)) for l in oroute["lamps"]]
+
+
+def run_sequence(ctx, oroute, lps, n, launches, pipeline, peek=None, toggle_at=None):
+    """`launches` = list of (lamp index, duration).  peek(k) is called between extend and accumulate."""
+    ctx.set_pipeline(pipeline)
+    ctx.resize_rays(n)
+    ctx.reset(True)
+    ctx.seed = 0
+    for k, (li, dur) in enumerate(launches):
+        if toggle_at is not None and k == toggle_at:
+            ctx.set_pipeline(not pipeline)
+        ctx.generate(lps[li], oroute["lightLength"], 0, n)
+        ctx.extend(n)
+        if peek is not None:
+            peek(k)
+        ctx.accumulate(dur)
+        ctx.shade(0, n * (k + 1) // 1, np.float32(44.0), oroute["minDosage"], False)
+    ctx.sync()
+    out = dict(sum=ctx.read_photon_map(0), max=ctx.read_photon_map(1), dose=ctx.read_dosage(),
+               color=ctx.read_color(), seed=ctx.seed)
+    ctx.set_pipeline(True)
+    return out
+
+
+def same(a, b):
+    return (np.array_equal(a["sum"], b["sum"]) and np.array_equal(a["max"], b["max"]) and
+            np.array_equal(bits(a["dose"]), bits(b["dose"])) and np.array_equal(bits(a["color"]), bits(b["color"]))
+            and a["seed"] == b["seed"])
+
+
+def test_pipelined_equals_one_stream_equals_oracle(ctx, orc, oscene, oroute):
+    lps = positions(orc, oscene, oroute)
+    n = 150000
+    launches = [(0, 60.0), (5, 10.0), (11, 35.0), (0, 60.0), (7, 1.0), (3, 20.0), (3, 20.0)]
+    a = run_sequence(ctx, oroute, lps, n, launches, True)
+    b = run_sequence(ctx, oroute, lps, n, launches, False)
+    c = run_sequence(ctx, oroute, lps, n, launches, True, toggle_at=3)
+    assert same(a, b) and same(a, c)
+    # the oracle, launch by launch
+    pm = np.zeros(oscene.T, dtype=np.float64)
+    mm = np.zeros(oscene.T, dtype=np.float64)
+    seed = 0
+    for li, dur in launches:
+        rays, seed = orc.generate(0, n, lps[li], oroute["lightLength"], seed)
+        temp = np.zeros(oscene.T, dtype=np.int32)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        orc.accumulate(pm, mm, temp, dur)
+    assert np.array_equal(a["sum"], pm) and np.array_equal(a["max"], mm) and a["seed"] == seed
+
+
+def test_reads_between_the_calls_of_a_launch(ctx, orc, oscene, oroute):
+    """read_counts between extend and accumulate (on alternating lanes) returns that launch's
+    counts and does not disturb the pipeline."""
+    lps = positions(orc, oscene, oroute)
+    n = 60000
+    launches = [(2, 5.0), (9, 5.0), (4, 7.0), (6, 9.0)]
+    seen = []
+    a = run_sequence(ctx, oroute, lps, n, launches, True, peek=lambda k: seen.append(ctx.read_counts()))
+    b = run_sequence(ctx, oroute, lps, n, launches, False)
+    assert same(a, b)
+    seed = 0
+    for k, (li, _) in enumerate(launches):
+        rays, seed = orc.generate(0, n, lps[li], oroute["lightLength"], seed)
+        temp = np.zeros(oscene.T, dtype=np.int32)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        assert np.array_equal(seen[k], temp), k
+
+
+def test_reset_and_rescene_in_the_middle(ctx, pkg, orc, oscene, oroute):
+    """reset, a scene swap to the two-triangle calibration scene and back (raytracer.cpp:166-224) and
+    a resize between pipelined launches."""
+    lps = positions(orc, oscene, oroute)
+    n = 40000
+    ref = run_sequence(ctx, oroute, lps, n, [(1, 3.0), (8, 4.0)], False)
+    ctx.set_pipeline(True)
+    ctx.resize_rays(n)
+    ctx.reset(True)
+    ctx.seed = 99
+    for li in (4, 6, 10):                           # work that must leave no trace
+        ctx.generate(lps[li], oroute["lightLength"], 0, n)
+        ctx.extend(n)
+        ctx.accumulate(1.0)
+    # calibration scene: one square of two triangles, root-leaf BVH
+    tris = np.zeros((2, 16), dtype=np.float32)
+    tris[0, [0, 1, 2]] = (-1, 0, -1); tris[0, [4, 5, 6]] = (1, 0, -1); tris[0, [8, 9, 10]] = (1, 0, 1)
+    tris[1, [0, 1, 2]] = (-1, 0, -1); tris[1, [4, 5, 6]] = (1, 0, 1); tris[1, [8, 9, 10]] = (-1, 0, 1)
+    nodes = np.zeros(1, dtype=orc.NODE_DT)
+    nodes[0] = (-1, 0, -1, 0, 1, 0, 1, 2)
+    ctx.set_scene(tris, nodes, np.array([0, 1], dtype=np.uint32))
+    ctx.resize_rays(1000)
+    ctx.generate((0.0, 0.5, 0.0), 1.0, 0, 1000)
+    ctx.extend(1000)
+    ctx.accumulate(1.0)
+    ctx.sync()
+    assert ctx.read_photon_map(0).sum() > 0
+    ctx.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+    got = run_sequence(ctx, oroute, lps, n, [(1, 3.0), (8, 4.0)], True)
+    assert same(got, ref)
