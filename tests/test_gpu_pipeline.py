@@ -121,3 +121,36 @@ def test_reset_and_rescene_in_the_middle(ctx, pkg, orc, oscene, oroute):
     ctx.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
     got = run_sequence(ctx, oroute, lps, n, [(1, 3.0), (8, 4.0)], True)
     assert same(got, ref)
+
+
+def test_record_renumbering_does_not_change_results(ctx, orc, oscene, oroute):
+    """uvrt_set_record_perm moves other node-pair records into the LDS-cached prefix of the default
+    kernel; any permutation must give the same counts (here: a random one and the reversal)."""
+    lps = positions(orc, oscene, oroute)
+    n = 80000
+    nodes = oscene.nodes                                     # inner nodes reachable from the root
+    q = [0] if nodes[0]["triCount"] == 0 else []
+    i = 0
+    while i < len(q):
+        l = int(nodes[q[i]]["leftFirst"]); i += 1
+        q += [l + k for k in (0, 1) if nodes[l + k]["triCount"] == 0]
+    npairs = len(q)
+    ctx.set_pipeline(True)
+    ctx.resize_rays(n)
+    rays, _ = orc.generate(0, n, lps[0], oroute["lightLength"], 5)
+    ref = np.zeros(oscene.T, dtype=np.int32)
+    orc.extend(ref, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+    rng = np.random.default_rng(0)
+    try:
+        for perm in (rng.permutation(npairs), np.arange(npairs)[::-1], None):
+            ctx.set_record_perm(perm)
+            ctx.reset(False)
+            ctx.seed = 5
+            ctx.generate(lps[0], oroute["lightLength"], 0, n)
+            ctx.extend(n)
+            assert np.array_equal(ctx.read_counts(), ref)
+            ctx.accumulate(1.0)
+        with pytest.raises(RuntimeError):
+            ctx.set_record_perm(np.zeros(npairs, dtype=np.uint32))      # not a permutation
+    finally:
+        ctx.set_record_perm(None)
