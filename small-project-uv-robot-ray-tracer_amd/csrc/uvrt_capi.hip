@@ -208,8 +208,8 @@ void split_bits(int bits, int& bphi, int& by, int& bo)
     by = bits - bo - bphi;
 }
 
-// Kernel selection (uvrt_set_variant).  0 (default) = extend v6 with the top-of-tree LDS cache and leaf
-// visits every third trip, falling back to the v4 kernel for scenes beyond v6's record numbering;
+// Kernel selection (uvrt_set_variant).  0 (default) = extend v6 with the top-of-tree LDS cache, leaf
+// visits every second trip and refill at 8 idle lanes, falling back to the v4 kernel for scenes beyond v6's record numbering;
 // 1-99 = the v1-v4 kernels (launch_extend; 90 = the former default); +100 = the same with IEEE divisions
 // everywhere; 200-299 = v5 (leaf period code + 10 * grid code), 300-399 = v5 with IEEE divisions;
 // 400-499 = v6 (code + 10 * grid code, uvrt_extend6.hip), 500-599 = v6 with IEEE divisions.
@@ -658,7 +658,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     if ((c->variant >= 100 && c->variant < 200) || (c->variant >= 300 && c->variant < 400) ||
         (c->variant >= 500 && c->variant < 600))
         p.force_exact = 1;
-    p.refill_min = c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
+    p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
     if (c->flavour != 0 && c->variant != 0 && c->variant != 90)
         return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default and the v4 kernel (variants 0, 90) only");
     if (c->variant >= 400 && c->variant < 900 && (size_t)c->npairs + (size_t)c->T >= (size_t)MAX_TRIS)
@@ -670,7 +670,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     }
     static const int per_cu5[5] = {8, 4, 6, 2, 16};
     const int g5 = (c->variant / 10) % 10;
-    const int code6 = c->variant == 0 ? 2 : c->variant % 10;
+    const int code6 = c->variant == 0 ? 1 : c->variant % 10;   // default: LDS top cache, leaf visits every 2nd trip
     if (v6 ? !launch_extend6(p, code6, per_cu5[g5 < 5 ? g5 : 0], ls)
         : v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], ls)
              : !launch_extend(p, c->variant % 100, ls))
