@@ -180,7 +180,9 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         // LDS copy of record r at byte 80 r: the 16 padding bytes spread the lanes of a ds_read_b128
         // over sixteen 4-bank windows (20 r mod 64) instead of four
         const uint32_t a0 = (uint32_t)(uintptr_t)s_top + cur * TOP6_STRIDE;
-        const char* recp = (const char*)p.recs + ((uint64_t)idx << 6);
+        // byte offset of the record: the shift drops the leaf flag and count bits of a reference
+        // (record indices are < 2^26: uvrt_capi.hip checks P + T), the base address is scalar
+        const uint32_t roff = cur << 6;
         unsigned long long save;
         asm volatile("s_mov_b64 %[save], exec\n\t"
                      "s_mov_b64 exec, %[mstk]\n\t"
@@ -191,15 +193,15 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
                      "ds_read_b128 %[w2], %[a0] offset:32\n\t"
                      "ds_read_b128 %[w3], %[a0] offset:48\n\t"
                      "s_mov_b64 exec, %[mglob]\n\t"
-                     "global_load_dwordx4 %[w0], %[rp], off\n\t"
-                     "global_load_dwordx4 %[w1], %[rp], off offset:16\n\t"
-                     "global_load_dwordx4 %[w2], %[rp], off offset:32\n\t"
-                     "global_load_dwordx4 %[w3], %[rp], off offset:48\n\t"
+                     "global_load_dwordx4 %[w0], %[ro], %[rb]\n\t"
+                     "global_load_dwordx4 %[w1], %[ro], %[rb] offset:16\n\t"
+                     "global_load_dwordx4 %[w2], %[ro], %[rb] offset:32\n\t"
+                     "global_load_dwordx4 %[w3], %[ro], %[rb] offset:48\n\t"
                      "s_mov_b64 exec, %[save]\n\t"
                      "s_waitcnt vmcnt(0) lgkmcnt(0)"
                      : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [st] "+v"(spec_top),
                        [save] "=&s"(save)
-                     : [a0] "v"(a0), [sa] "v"(sa), [rp] "v"(recp),
+                     : [a0] "v"(a0), [sa] "v"(sa), [ro] "v"(roff), [rb] "s"(p.recs),
                        [mtop] "s"(m_top), [mglob] "s"(m_glob), [mstk] "s"(m_stk)
                      : "memory");
     }
