@@ -222,8 +222,9 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
             h1 = box_fast(x1, y1, z1, L.po.y, d1);
         }
         // extend.cl:56-76 with dist = 1e30f for a missed child: nearer first, farther pushed
-        const float D0 = h0 ? d0 : 1e30f, D1 = h1 ? d1 : 1e30f;
-        const bool sw = D0 > D1;
+        // dist1 > dist2 of extend.cl:61 with 1e30f standing for a miss: child 1 first iff it is hit and
+        // child 0 is missed or farther (a hit distance is < dist <= 1e30f, so the sentinel never ties)
+        const bool sw = h1 & (!h0 | (d0 > d1));
         const uint32_t r0 = __float_as_uint(w3.x), r1 = __float_as_uint(w3.y);
         const uint32_t nearer = sw ? r1 : r0, farther = sw ? r0 : r1;
         if (h0 & h1) {
@@ -252,7 +253,7 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         uint32_t popped = spec_top;                        // REF_DONE when the stack is empty
         if (L.sp > PS6) popped = ovf_ptr(p)[L.sp - 1 - PS6];
         L.cur = popped;
-        L.sp = L.sp > 0 ? L.sp - 1 : 0;
+        L.sp = (int)__builtin_elementwise_sub_sat((uint32_t)L.sp, 1u);
     }
 }
 
