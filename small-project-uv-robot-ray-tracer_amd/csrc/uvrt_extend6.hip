@@ -154,7 +154,8 @@ __device__ __forceinline__ uint32_t* ovf_ptr(const ExtendParams& p)
 // arithmetic of the box and triangle tests differs.
 template <bool TOP>
 __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t stack_base,
-                                      const float4* s_top, uint32_t top_pairs, bool leaf_trip, bool exact)
+                                      const float4* s_top, uint32_t top_pairs, bool leaf_trip, bool exact,
+                                      unsigned long long m_act /* lanes holding a ray */)
 {
     const uint32_t cur = L.cur;
     const bool is_inner = cur < REF_LEAF_BIT;
@@ -171,7 +172,6 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         // lane masks from single comparisons, combined as 64-bit integers (SALU): a ballot of a
         // compound condition would go through a v_cndmask / v_cmp pair
         const unsigned long long m_in = __builtin_amdgcn_ballot_w64(cur < REF_LEAF_BIT);
-        const unsigned long long m_act = __builtin_amdgcn_ballot_w64(cur != REF_DONE);
         const unsigned long long m_top = TOP ? __builtin_amdgcn_ballot_w64(cur < top_pairs) : 0ull;
         const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(L.sp > 0);
         const unsigned long long m_go = m_in | (leaf_trip ? (m_act & ~m_in) : 0ull);
@@ -206,6 +206,21 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
                      : "memory");
     }
     bool need_pop = is_leaf;
+    if (is_leaf) {                                         // extend.cl:48-55 (before the inner-node block:
+                                                           // the old reference is dead once that block assigns the new one)
+        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
+        const uint32_t first = idx - (uint32_t)p.npairs;
+        if (count == 15u) count = p.scene.leaf_count[first];
+        float dist = L.po.y;
+        tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+             make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
+             make_float4(w2.x, w2.y, w2.z, w2.w), exact);
+        for (uint32_t i = 1; i < count; ++i) {
+            const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
+            tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
+        }
+        L.po.y = dist;
+    }
     if (is_inner) {
         float d0, d1;
         bool h0, h1;
@@ -235,19 +250,6 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         }
         need_pop = !(h0 | h1);
         L.cur = nearer;
-    } else if (is_leaf) {                                  // extend.cl:48-55
-        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
-        const uint32_t first = idx - (uint32_t)p.npairs;
-        if (count == 15u) count = p.scene.leaf_count[first];
-        float dist = L.po.y;
-        tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
-             make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
-             make_float4(w2.x, w2.y, w2.z, w2.w), exact);
-        for (uint32_t i = 1; i < count; ++i) {
-            const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
-            tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
-        }
-        L.po.y = dist;
     }
     if (need_pop) {
         uint32_t popped = spec_top;                        // REF_DONE when the stack is empty
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __builtin_amdgcn_ballot_w64(L.cur < REF_LEAF_BIT) == 0;
             ++trip;
         }
-        step6<TOP>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0);
+        step6<TOP>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0, act);
     }
     // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
     if (RECORD && live && p.hits) {
