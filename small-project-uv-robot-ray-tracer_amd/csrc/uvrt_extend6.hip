@@ -129,6 +129,19 @@ __device__ __forceinline__ void tri6(float ox, float oy, float oz, float dx, flo
     }
 }
 
+// In-place update of a loop-carried value inside a divergent branch: the write happens under the
+// branch's exec mask into the SAME register, so hipcc has no second copy of the value to merge (it
+// otherwise keeps a loop-carried and an in-body copy of the ray constants and moves one into the
+// other on every trip).
+__device__ __forceinline__ void set_in_place(float& dst, float v) { asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(v)); }
+__device__ __forceinline__ void set_in_place(uint32_t& dst, uint32_t v) { asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(v)); }
+__device__ __forceinline__ void set_in_place(int& dst, int v) { asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(v)); }
+__device__ __forceinline__ void set_in_place(v2f& dst, float lo, float hi)
+{
+    const v2f v = {lo, hi};
+    asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "+v"(dst) : "v"(v));
+}
+
 struct Lane6 {
     v2f px, py, pz;         // {d, RN32(1/d)} per axis
     v2f po;                 // {origin y, dist}
@@ -316,14 +329,14 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                     const float4 rec = p.rays[my];
                     // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
                     // and never use y)
-                    L.px = (v2f){rec.x, rcp_exact(rec.x)};
-                    L.py = (v2f){rec.y, rcp_exact(rec.y)};
-                    L.pz = (v2f){rec.z, rcp_exact(rec.z)};
-                    L.po = (v2f){rec.w, 1e30f};            // generate.cl:34-35
-                    L.triID = 0;
+                    set_in_place(L.px, rec.x, rcp_exact(rec.x));
+                    set_in_place(L.py, rec.y, rcp_exact(rec.y));
+                    set_in_place(L.pz, rec.z, rcp_exact(rec.z));
+                    set_in_place(L.po, rec.w, 1e30f);       // generate.cl:34-35
+                    set_in_place(L.triID, 0u);
                     if (RECORD) { slot = my; live = true; }
-                    L.sp = 0;
-                    L.cur = p.root_ref6;
+                    set_in_place(L.sp, 0);
+                    set_in_place(L.cur, p.root_ref6);
                     const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
                     const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
                     spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
