@@ -21,7 +21,7 @@ for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
             a = agg[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 avg = {k: v[0] / v[1] for k, v in agg.items()}
 fetch_kb, write_kb = avg.get("FETCH_SIZE", 0.0), avg.get("WRITE_SIZE", 0.0)
-out = {"kernel": "k_extend6<3, false, true> (default)", "rays_per_launch": 2073600, "launches_averaged": int(agg["FETCH_SIZE"][1]),
+out = {"kernel": "k_extend6<2, false, true> (default)", "rays_per_launch": 2073600, "launches_averaged": int(agg["FETCH_SIZE"][1]),
        "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "raw": avg,
        "method": "rocprofv3 --pmc, one pass per counter; read bytes = FETCH_SIZE*1024*2 (gfx950: 128-B requests "
                  "tallied as 64 B), write bytes = WRITE_SIZE*1024 (each deposit atomic counts as one 32-B write)",
