@@ -305,7 +305,9 @@ def main():
                     "rays_per_launch": rt.photonsPerLight, "avg_launch_ms": round(avg_ms, 4),
                     "extend_mray_s": round(rt.photonsPerLight / avg_ms / 1e3, 1),
                     "timing_pass": "%d step(s) with launch pipelining off after the timed region; HIP events "
-                                   "around uvrt_extend on its stream" % timing_steps}
+                                   "around uvrt_extend on its stream" % timing_steps,
+                    "note": "frac > 1 because the scene (5.7 MB) is L2/LDS resident: measured HBM traffic is far "
+                            "below the algorithmic bytes; the kernel is bound by VALU instruction issue (DESIGN.md 4)"}
         out = {
             "metric": "Mray/s (extend+shade) on C046_1.glb 1920x1080x8-bounce", "value": round(value, 2),
             "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
