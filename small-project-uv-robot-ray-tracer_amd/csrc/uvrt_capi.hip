@@ -100,17 +100,22 @@ struct uvrt_ctx {
     // shade) alternate between the context's stream and an internal side stream, each with its own
     // ray, record, count and overflow-stack buffers, so that the next launch fills the wave slots the
     // draining launch frees.  The per-triangle maps are updated in launch order (event waits).
+    static constexpr int MAXL = 4;    // lane 0 = the context's stream and the buffers above
     bool pipeline = true;             // uvrt_set_pipeline
+    int nlanes = 2;                   // developer knob UVRT_LANES (1..MAXL): 3 gain ~1 %, 4 (with 4 workgroups
+                                      // per CU) win only for long launch sequences (profiles/r01_v6_experiments.txt)
     bool ext_touch = false;           // a device pointer was handed out since the last fence
     int lane = 0;                     // lane of the current launch (uvrt_generate selects it)
-    hipStream_t side = nullptr;
-    bool side_used = false;           // the side stream holds work the main stream is not ordered after
+    int prev_lane = 0;                // lane of the launch before it (the maps are updated in launch order)
+    bool cur_pipelined = false;       // the current launch takes part in the lane rotation
+    hipStream_t side[MAXL] = {};      // [0] unused
+    bool side_used[MAXL] = {};        // the side stream holds work the main stream is not ordered after
     hipEvent_t ev_fence = nullptr;    // on the main stream, after the last context-wide operation
-    hipEvent_t ev_tail = nullptr;     // scratch: tail of "the other" stream
-    uint64_t fence_seq = 0, side_seen_fence = 0;
-    DevBuf rays2, recs2, counts2, ovf2;
-    bool recs_valid2 = false;
-    float recs_ox2 = 0, recs_oz2 = 0;
+    hipEvent_t ev_tail[MAXL] = {};    // tail of a lane's stream
+    uint64_t fence_seq = 0, side_seen_fence[MAXL] = {};
+    DevBuf xrays[MAXL], xrecs[MAXL], xcounts[MAXL], xovf[MAXL];   // [0] unused: lane 0 has rays, recs, counts, ovf_stack
+    bool xrecs_valid[MAXL] = {};
+    float xrecs_ox[MAXL] = {}, xrecs_oz[MAXL] = {};
 
     // generate.cl:6 program-scope SEED
     uint32_t seed = 0;
@@ -137,13 +142,16 @@ int set_device(uvrt_ctx* c)
 }
 
 // ---- launch lanes ----
-// the main stream becomes ordered after everything the side stream holds
+hipStream_t stream_of(uvrt_ctx* c, int l) { return l == 0 ? c->stream : c->side[l]; }
+// the main stream becomes ordered after everything the side streams hold
 int join_all(uvrt_ctx* c)
 {
-    if (!c->side_used) return UVRT_OK;
-    HIP_TRY(hipEventRecord(c->ev_tail, c->side));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
-    c->side_used = false;
+    for (int l = 1; l < uvrt_ctx::MAXL; ++l) {
+        if (!c->side_used[l]) continue;
+        HIP_TRY(hipEventRecord(c->ev_tail[l], c->side[l]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail[l], 0));
+        c->side_used[l] = false;
+    }
     return UVRT_OK;
 }
 // a context-wide operation has been enqueued on the main stream: later side-stream work waits for it
@@ -153,35 +161,39 @@ int mark_fence(uvrt_ctx* c)
     ++c->fence_seq;
     return UVRT_OK;
 }
-// stream of the current lane; the side stream first catches up with the last context-wide operation
+// stream of the current lane; a side stream first catches up with the last context-wide operation
 int lane_stream(uvrt_ctx* c, hipStream_t* out)
 {
-    if (c->lane == 0) { *out = c->stream; return UVRT_OK; }
+    const int l = c->lane;
+    if (l == 0) { *out = c->stream; return UVRT_OK; }
     if (c->ext_touch) {   // external work (e.g. an RCCL reduction on the maps) sits on the main stream
         c->ext_touch = false;
         if (int rc = mark_fence(c)) return rc;
     }
-    if (c->fence_seq != c->side_seen_fence) {
-        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fence, 0));
-        c->side_seen_fence = c->fence_seq;
+    if (c->fence_seq != c->side_seen_fence[l]) {
+        HIP_TRY(hipStreamWaitEvent(c->side[l], c->ev_fence, 0));
+        c->side_seen_fence[l] = c->fence_seq;
     }
-    c->side_used = true;
-    *out = c->side;
+    c->side_used[l] = true;
+    *out = c->side[l];
     return UVRT_OK;
 }
-// the current lane's stream becomes ordered after everything the other lane's stream holds
-int order_after_other(uvrt_ctx* c)
+// the current lane's stream becomes ordered after everything the previous launch's lane holds (its
+// accumulate and Shade): the per-triangle maps are updated in launch order
+int order_after_previous(uvrt_ctx* c)
 {
-    if (c->lane == 0) return join_all(c);
-    HIP_TRY(hipEventRecord(c->ev_tail, c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_tail, 0));
-    c->side_used = true;
+    const int l = c->lane, q = c->prev_lane;
+    if (q == l) return UVRT_OK;
+    if (l == 0) return join_all(c);
+    HIP_TRY(hipEventRecord(c->ev_tail[q], stream_of(c, q)));
+    HIP_TRY(hipStreamWaitEvent(c->side[l], c->ev_tail[q], 0));
+    c->side_used[l] = true;
     return UVRT_OK;
 }
-DevBuf& lane_rays(uvrt_ctx* c) { return c->lane ? c->rays2 : c->rays; }
-DevBuf& lane_recs(uvrt_ctx* c) { return c->lane ? c->recs2 : c->recs; }
-DevBuf& lane_counts(uvrt_ctx* c) { return c->lane ? c->counts2 : c->counts; }
-DevBuf& lane_ovf(uvrt_ctx* c) { return c->lane ? c->ovf2 : c->ovf_stack; }
+DevBuf& lane_rays(uvrt_ctx* c) { return c->lane ? c->xrays[c->lane] : c->rays; }
+DevBuf& lane_recs(uvrt_ctx* c) { return c->lane ? c->xrecs[c->lane] : c->recs; }
+DevBuf& lane_counts(uvrt_ctx* c) { return c->lane ? c->xcounts[c->lane] : c->counts; }
+DevBuf& lane_ovf(uvrt_ctx* c) { return c->lane ? c->xovf[c->lane] : c->ovf_stack; }
 
 // work-item 0's RNG walk of cl/generate.cl:13-39 on the host (strict f32/f64, same order)
 uint32_t host_wang_hash(uint32_t s)
@@ -264,9 +276,12 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     HIP_TRY(hipSetDevice(device_id));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (int l = 0; l < uvrt_ctx::MAXL; ++l) {
+        if (l > 0) HIP_TRY(hipStreamCreateWithFlags(&c->side[l], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[l], hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    if (const char* e = getenv("UVRT_LANES")) { const int v = atoi(e); if (v >= 1 && v <= uvrt_ctx::MAXL) c->nlanes = v; }
     if (const char* e = getenv("UVRT_PIPELINE")) c->pipeline = atoi(e) != 0;   // developer knob
     int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
@@ -281,11 +296,13 @@ void uvrt_destroy(uvrt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->side) (void)hipStreamSynchronize(c->side);
-    for (DevBuf* b : {&c->rays2, &c->recs2, &c->counts2, &c->ovf2}) b->release();
+    for (int l = 0; l < uvrt_ctx::MAXL; ++l) {
+        if (c->side[l]) (void)hipStreamSynchronize(c->side[l]);
+        for (DevBuf* b : {&c->xrays[l], &c->xrecs[l], &c->xcounts[l], &c->xovf[l]}) b->release();
+        if (c->ev_tail[l]) (void)hipEventDestroy(c->ev_tail[l]);
+        if (c->side[l]) (void)hipStreamDestroy(c->side[l]);
+    }
     if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
-    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
-    if (c->side) (void)hipStreamDestroy(c->side);
     for (DevBuf* b : {&c->pairs, &c->lpairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
@@ -394,14 +411,16 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
     if ((rc = c->lpairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
     if ((rc = c->recs.ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
-    if ((rc = c->recs2.ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
+    for (int l = 1; l < c->nlanes; ++l)
+        if ((rc = c->xrecs[l].ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
     // + 16 bytes: the merged record fetch of the traversal reads 64 bytes at every leaf record
     if ((rc = c->ltris.ensure((size_t)T * sizeof(LeafTri) + 16, true, c->stream))) return rc;
     if ((rc = c->leaf_count.ensure((size_t)T * 4, false, c->stream))) return rc;
     if ((rc = c->area.ensure((size_t)T * 4, false, c->stream))) return rc;
     if (resized || !c->photon_map.p) {
         // raytracer.cpp:32-37 (the reference leaves them uninitialised until reset; zero here)
-        for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->counts2, &c->dosage, &c->color}) b->release();
+        for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->xcounts[1], &c->xcounts[2], &c->xcounts[3],
+                          &c->dosage, &c->color}) b->release();
         if ((rc = c->photon_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         if ((rc = c->max_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         // up to 64 deposit replicas, at most 64 MiB in total
@@ -409,7 +428,8 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         while (R > 1 && (size_t)R * (size_t)T * 4 > ((size_t)64 << 20)) R >>= 1;
         c->replicas = R;
         if ((rc = c->counts.ensure((size_t)R * (size_t)T * 4, true, c->stream))) return rc;
-        if ((rc = c->counts2.ensure((size_t)R * (size_t)T * 4, true, c->stream))) return rc;
+        for (int l = 1; l < c->nlanes; ++l)
+            if ((rc = c->xcounts[l].ensure((size_t)R * (size_t)T * 4, true, c->stream))) return rc;
         if ((rc = c->dosage.ensure((size_t)T * 4, true, c->stream))) return rc;
         if ((rc = c->color.ensure((size_t)T * 36, true, c->stream))) return rc;
     }
@@ -426,7 +446,8 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         launch_prepare_scene(d_tris.as<float4>(), d_idx.as<uint32_t>(), c->ltris.as<LeafTri>(),
                              c->area.as<float>(), T, c->stream);
         launch_prepare_leaves6(c->ltris.as<LeafTri>(), c->recs.p, (int32_t)pairs.size(), T, c->stream);
-        launch_prepare_leaves6(c->ltris.as<LeafTri>(), c->recs2.p, (int32_t)pairs.size(), T, c->stream);
+        for (int l = 1; l < c->nlanes; ++l)
+            launch_prepare_leaves6(c->ltris.as<LeafTri>(), c->xrecs[l].p, (int32_t)pairs.size(), T, c->stream);
         e1 = hipGetLastError();
         e2 = hipStreamSynchronize(c->stream);
     }
@@ -439,7 +460,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->top_pairs = top_pairs;
     c->npairs = (int32_t)pairs.size();
     c->recs_valid = false;
-    c->recs_valid2 = false;
+    for (int l = 0; l < uvrt_ctx::MAXL; ++l) c->xrecs_valid[l] = false;
     c->have_perm = false;
     c->have_scene = true;
     c->scene_force_exact = tiny_bound || huge_vertex;
@@ -457,7 +478,8 @@ int uvrt_resize_rays(uvrt_ctx* c, int64_t photon_count)
     int rc;
     const size_t n = (size_t)photon_count;
     if ((rc = c->rays.ensure(n * 16, false, c->stream))) return rc;
-    if ((rc = c->rays2.ensure(n * 16, false, c->stream))) return rc;
+    for (int l = 1; l < c->nlanes; ++l)
+        if ((rc = c->xrays[l].ensure(n * 16, false, c->stream))) return rc;
     if ((rc = c->keyrank.ensure(n * 8, false, c->stream))) return rc;
     if ((rc = c->sorted.ensure(n * 16, false, c->stream))) return rc;
     if ((rc = c->order.ensure(n * 4, false, c->stream))) return rc;
@@ -477,7 +499,8 @@ int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
     launch_reset(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
                  c->replicas, c->T, c->color.as<float>(), reset_color, c->T, c->stream);
     HIP_TRY(hipGetLastError());
-    if (c->counts2.p) HIP_TRY(hipMemsetAsync(c->counts2.p, 0, c->counts2.bytes, c->stream));
+    for (int l = 1; l < uvrt_ctx::MAXL; ++l)
+        if (c->xcounts[l].p) HIP_TRY(hipMemsetAsync(c->xcounts[l].p, 0, c->xcounts[l].bytes, c->stream));
     return mark_fence(c);
 }
 
@@ -519,12 +542,15 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (bits > 20) bits = 20;
     // launch lane: alternate between the two streams / buffer sets when nothing stands against it
     {
-        const bool pipe_ok = c->pipeline && variant_is_v6(c) && !c->record_hits && bits == 0 && c->rays2.p;
-        if (pipe_ok) c->lane ^= 1;
+        const bool pipe_ok = c->pipeline && c->nlanes > 1 && variant_is_v6(c) && !c->record_hits && bits == 0 &&
+                             c->xrays[1].p;
+        c->prev_lane = c->lane;
+        c->cur_pipelined = pipe_ok;
+        if (pipe_ok) c->lane = (c->lane + 1) % c->nlanes;
         else { if (int rc = join_all(c)) return rc; c->lane = 0; }
-        if (c->lane == 1) {
-            // 8 workgroups per CU x 256 threads x 24 overflow entries (the default kernel's grid)
-            if (int rc = c->ovf2.ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream)) return rc;
+        if (c->lane != 0) {
+            // 8 workgroups per CU x 256 threads x 24 overflow entries (the largest grid a side lane runs)
+            if (int rc = c->xovf[c->lane].ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream)) return rc;
         }
     }
     hipStream_t ls;
@@ -566,9 +592,9 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     }
     launch_generate(p, ls);
     HIP_TRY(hipGetLastError());
-    (c->lane ? c->recs_valid2 : c->recs_valid) = p.prep_recs != nullptr;
-    (c->lane ? c->recs_ox2 : c->recs_ox) = lp[0];
-    (c->lane ? c->recs_oz2 : c->recs_oz) = lp[2];
+    (c->lane ? c->xrecs_valid[c->lane] : c->recs_valid) = p.prep_recs != nullptr;
+    (c->lane ? c->xrecs_ox[c->lane] : c->recs_ox) = lp[0];
+    (c->lane ? c->xrecs_oz[c->lane] : c->recs_oz) = lp[2];
     if (p.keyrank) {
         launch_scan_bins(c->hist.as<uint32_t>(), c->bin_start.as<uint32_t>(), 1 << bits, c->stream);
         launch_scatter(c->rays.as<float4>(), c->keyrank.as<uint2>(), c->bin_start.as<uint32_t>(),
@@ -636,8 +662,8 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
     p.perm_root = c->perm_root;
     {
-        const bool valid = c->lane ? c->recs_valid2 : c->recs_valid;
-        const float rox = c->lane ? c->recs_ox2 : c->recs_ox, roz = c->lane ? c->recs_oz2 : c->recs_oz;
+        const bool valid = c->lane ? c->xrecs_valid[c->lane] : c->recs_valid;
+        const float rox = c->lane ? c->xrecs_ox[c->lane] : c->recs_ox, roz = c->lane ? c->xrecs_oz[c->lane] : c->recs_oz;
         p.recs_prepared = (valid && memcmp(&rox, &c->ox, 4) == 0 && memcmp(&roz, &c->oz, 4) == 0) ? 1 : 0;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -671,7 +697,10 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     static const int per_cu5[5] = {8, 4, 6, 2, 16};
     const int g5 = (c->variant / 10) % 10;
     const int code6 = c->variant == 0 ? 1 : c->variant % 10;   // default: LDS top cache, leaf visits every 2nd trip
-    if (v6 ? !launch_extend6(p, code6, per_cu5[g5 < 5 ? g5 : 0], ls)
+    // default grid: 8 workgroups per CU on one stream; with four launch lanes 4 per CU (two launches
+    // co-resident fill the GPU, every wave owns twice the rays: a shorter drain per ray)
+    const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : 8;
+    if (v6 ? !launch_extend6(p, code6, c->variant == 0 ? per_cu_default : per_cu5[g5 < 5 ? g5 : 0], ls)
         : v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], ls)
              : !launch_extend(p, c->variant % 100, ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
@@ -688,7 +717,7 @@ int uvrt_accumulate(uvrt_ctx* c, float time_step, int32_t tri_count)
     if (int rc = set_device(c)) return rc;
     // the maps are updated in launch order: wait for whatever the other lane has enqueued so far
     // (its accumulate and shade), not for this lane's successor
-    if (int rc = order_after_other(c)) return rc;
+    if (int rc = order_after_previous(c)) return rc;
     hipStream_t ls;
     if (int rc = lane_stream(c, &ls)) return rc;
     launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), lane_counts(c).as<int32_t>(),
@@ -734,7 +763,7 @@ int uvrt_set_record_perm(uvrt_ctx* c, const uint32_t* perm, int32_t n)
     if (int rc = join_all(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->recs_valid = false;
-    c->recs_valid2 = false;
+    for (int l = 0; l < uvrt_ctx::MAXL; ++l) c->xrecs_valid[l] = false;
     if (!perm) { c->have_perm = false; return UVRT_OK; }
     if (n != c->npairs) return fail(UVRT_ERR_INVALID, "uvrt_set_record_perm: %d entries, the scene has %d inner nodes", n, c->npairs);
     std::vector<uint8_t> seen((size_t)n, 0);
@@ -910,6 +939,7 @@ int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
     }
     if (int rc = join_all(c)) return rc;
     c->lane = 0;
+    c->cur_pipelined = false;
     HIP_TRY(hipMemcpyAsync(c->rays.p, packed.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     for (int k = 0; k < 3; ++k)
         HIP_TRY(hipMemcpyAsync((char*)c->recip.p + (size_t)k * c->capacity * 8, rec.data() + (size_t)k * n,

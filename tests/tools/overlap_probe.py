@@ -17,6 +17,8 @@ n = 2073600
 ctxs = [pkg.capi.Ctx(0) for _ in range(3)]
 for c in ctxs:
     c.set_scene(s.tris, s.nodes, s.triIdx); c.resize_rays(n); c.reset(False)
+    c.set_variant(int(os.environ.get("VARIANT", "0")))
+    c.set_pipeline(os.environ.get("PIPE", "0") == "1")      # PIPE=1: every context also pipelines over its two lanes
 
 
 def run(cs, launches=32):
@@ -31,5 +33,5 @@ def run(cs, launches=32):
 
 
 for rnd in range(3):
-    print("one stream: %.3f ms per launch   two streams: %.3f   three streams: %.3f"
+    print("one context: %.3f ms per launch   two contexts: %.3f   three contexts: %.3f"
           % (run(ctxs[:1]), run(ctxs[:2]), run(ctxs[:3])), flush=True)
