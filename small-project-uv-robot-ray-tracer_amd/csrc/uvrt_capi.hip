@@ -104,7 +104,11 @@ struct uvrt_ctx {
     bool pipeline = true;             // uvrt_set_pipeline
     int nlanes = 2;                   // developer knob UVRT_LANES (1..MAXL): 3 gain ~1 %, 4 (with 4 workgroups
                                       // per CU) win only for long launch sequences (profiles/r01_v6_experiments.txt)
-    bool ext_touch = false;           // a device pointer was handed out since the last fence
+    bool ext_touch = false;           // a count-buffer pointer was handed out since the last fence
+    bool ext_touch_maps = false;      // a map / dose / colour pointer was handed out since the last map fence
+    bool counts_dirty[MAXL] = {};     // the lane's count buffer holds deposits that were not accumulated
+    hipEvent_t ev_mapfence = nullptr; // on the main stream, after the last operation on the per-triangle maps
+    uint64_t mapfence_seq = 0, side_seen_mapfence[MAXL] = {};
     int lane = 0;                     // lane of the current launch (uvrt_generate selects it)
     int prev_lane = 0;                // lane of the launch before it (the maps are updated in launch order)
     bool cur_pipelined = false;       // the current launch takes part in the lane rotation
@@ -161,18 +165,31 @@ int mark_fence(uvrt_ctx* c)
     ++c->fence_seq;
     return UVRT_OK;
 }
-// stream of the current lane; a side stream first catches up with the last context-wide operation
-int lane_stream(uvrt_ctx* c, hipStream_t* out)
+// an operation on the per-triangle maps (reset, an external reduction) has been enqueued on the main
+// stream: later accumulate / Shade work on side streams waits for it -- generate and extend do not,
+// so the first launches of the next computation overlap the drain of the previous one
+int mark_map_fence(uvrt_ctx* c)
 {
+    HIP_TRY(hipEventRecord(c->ev_mapfence, c->stream));
+    ++c->mapfence_seq;
+    return UVRT_OK;
+}
+// stream of the current lane; a side stream first catches up with the last context-wide operation
+// and, for work on the maps (`maps`), with the last operation on them
+int lane_stream(uvrt_ctx* c, hipStream_t* out, bool maps = false)
+{
+    // external work enqueued on the main stream since a device pointer was handed out
+    if (c->ext_touch) { c->ext_touch = false; if (int rc = mark_fence(c)) return rc; }
+    if (c->ext_touch_maps) { c->ext_touch_maps = false; if (int rc = mark_map_fence(c)) return rc; }
     const int l = c->lane;
     if (l == 0) { *out = c->stream; return UVRT_OK; }
-    if (c->ext_touch) {   // external work (e.g. an RCCL reduction on the maps) sits on the main stream
-        c->ext_touch = false;
-        if (int rc = mark_fence(c)) return rc;
-    }
     if (c->fence_seq != c->side_seen_fence[l]) {
         HIP_TRY(hipStreamWaitEvent(c->side[l], c->ev_fence, 0));
         c->side_seen_fence[l] = c->fence_seq;
+    }
+    if (maps && c->mapfence_seq != c->side_seen_mapfence[l]) {
+        HIP_TRY(hipStreamWaitEvent(c->side[l], c->ev_mapfence, 0));
+        c->side_seen_mapfence[l] = c->mapfence_seq;
     }
     c->side_used[l] = true;
     *out = c->side[l];
@@ -281,6 +298,7 @@ int uvrt_create(int device_id, uvrt_ctx** out)
         HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[l], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_mapfence, hipEventDisableTiming));
     if (const char* e = getenv("UVRT_LANES")) { const int v = atoi(e); if (v >= 1 && v <= uvrt_ctx::MAXL) c->nlanes = v; }
     if (const char* e = getenv("UVRT_PIPELINE")) c->pipeline = atoi(e) != 0;   // developer knob
     int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
@@ -303,6 +321,7 @@ void uvrt_destroy(uvrt_ctx* c)
         if (c->side[l]) (void)hipStreamDestroy(c->side[l]);
     }
     if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
+    if (c->ev_mapfence) (void)hipEventDestroy(c->ev_mapfence);
     for (DevBuf* b : {&c->pairs, &c->lpairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
@@ -499,9 +518,18 @@ int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
     launch_reset(c->photon_map.as<double>(), c->max_map.as<double>(), c->counts.as<int32_t>(),
                  c->replicas, c->T, c->color.as<float>(), reset_color, c->T, c->stream);
     HIP_TRY(hipGetLastError());
-    for (int l = 1; l < uvrt_ctx::MAXL; ++l)
-        if (c->xcounts[l].p) HIP_TRY(hipMemsetAsync(c->xcounts[l].p, 0, c->xcounts[l].bytes, c->stream));
-    return mark_fence(c);
+    // side-lane count buffers are zero unless an extend was never accumulated; only then must later
+    // generate / extend work on the side streams wait for this reset
+    bool dirty = false;
+    for (int l = 1; l < uvrt_ctx::MAXL; ++l) {
+        if (c->counts_dirty[l] && c->xcounts[l].p) {
+            HIP_TRY(hipMemsetAsync(c->xcounts[l].p, 0, c->xcounts[l].bytes, c->stream));
+            dirty = true;
+        }
+        c->counts_dirty[l] = false;
+    }
+    c->counts_dirty[0] = false;
+    return dirty ? mark_fence(c) : mark_map_fence(c);
 }
 
 uint32_t uvrt_seed_next(const float lp[3], float light_length, uint32_t seed_prev)
@@ -706,6 +734,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, ls));
+    c->counts_dirty[c->lane] = true;
     c->last_extended = c->record_hits;
     return UVRT_OK;
 }
@@ -719,9 +748,10 @@ int uvrt_accumulate(uvrt_ctx* c, float time_step, int32_t tri_count)
     // (its accumulate and shade), not for this lane's successor
     if (int rc = order_after_previous(c)) return rc;
     hipStream_t ls;
-    if (int rc = lane_stream(c, &ls)) return rc;
+    if (int rc = lane_stream(c, &ls, true)) return rc;
     launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), lane_counts(c).as<int32_t>(),
                       c->replicas, c->T, time_step, tri_count, ls);
+    if (tri_count == c->T) c->counts_dirty[c->lane] = false;
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -736,7 +766,7 @@ int uvrt_compute_dosage(uvrt_ctx* c, int32_t which, int32_t photons_per_light, f
     if (int rc = set_device(c)) return rc;
     const double* map = which == UVRT_MAP_SUM ? c->photon_map.as<double>() : c->max_map.as<double>();
     hipStream_t ls;
-    if (int rc = lane_stream(c, &ls)) return rc;
+    if (int rc = lane_stream(c, &ls, true)) return rc;
     launch_compute_dosage(map, c->dosage.as<float>(), c->area.as<float>(), photons_per_light,
                           scaled_power, tri_count, ls);
     HIP_TRY(hipGetLastError());
@@ -749,7 +779,7 @@ int uvrt_dosage_to_color(uvrt_ctx* c, float min_value, int32_t threshold_view, i
         return fail(UVRT_ERR_INVALID, "uvrt_dosage_to_color: bad tri_count");
     if (int rc = set_device(c)) return rc;
     hipStream_t ls;
-    if (int rc = lane_stream(c, &ls)) return rc;
+    if (int rc = lane_stream(c, &ls, true)) return rc;
     launch_dosage_to_color(c->dosage.as<float>(), c->color.as<float>(), min_value, threshold_view,
                            tri_count, ls);
     HIP_TRY(hipGetLastError());
@@ -790,7 +820,7 @@ int uvrt_shade(uvrt_ctx* c, int32_t which, int32_t photons_per_light, float scal
     if (int rc = set_device(c)) return rc;
     const double* map = which == UVRT_MAP_SUM ? c->photon_map.as<double>() : c->max_map.as<double>();
     hipStream_t ls;
-    if (int rc = lane_stream(c, &ls)) return rc;
+    if (int rc = lane_stream(c, &ls, true)) return rc;
     launch_shade(map, c->dosage.as<float>(), c->area.as<float>(), c->color.as<float>(), photons_per_light,
                  scaled_power, min_value, threshold_view, tri_count, ls);
     HIP_TRY(hipGetLastError());
@@ -978,7 +1008,9 @@ int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
     }
     *ptr = b->p;
     *bytes = (int64_t)((size_t)c->T * elem);
-    c->ext_touch = true;      // see lane_stream(): the next side-lane work waits for the main stream's tail
+    // see lane_stream(): the next side-lane work (on the maps: the next accumulate / Shade) waits for
+    // what the caller enqueues on the main stream up to the next call
+    if (which == 2) c->ext_touch = true; else c->ext_touch_maps = true;
     return UVRT_OK;
 }
 
