@@ -154,3 +154,45 @@ def test_record_renumbering_does_not_change_results(ctx, orc, oscene, oroute):
             ctx.set_record_perm(np.zeros(npairs, dtype=np.uint32))      # not a permutation
     finally:
         ctx.set_record_perm(None)
+
+
+def test_back_to_back_computations_without_host_sync(ctx, orc, oscene, oroute):
+    """Several computations (reset + launches) enqueued back to back: the next one's first launches
+    overlap the previous one's drain (map fence), yet each reset must see all earlier map updates
+    finished and each accumulate the reset before it.  One computation ends with an extend that is
+    never accumulated (dirty count buffers: the reset then fences everything)."""
+    lps = positions(orc, oscene, oroute)
+    n = 50000
+
+    def computation(k, leave_dirty):
+        ctx.reset(True)
+        ctx.seed = k
+        for j, li in enumerate((k % 12, (k + 5) % 12, (k + 7) % 12)):
+            ctx.generate(lps[li], oroute["lightLength"], 0, n)
+            ctx.extend(n)
+            if leave_dirty and j == 2:
+                break
+            ctx.accumulate(10.0 + k)
+            ctx.shade(0, n, np.float32(44.0), oroute["minDosage"], False)
+
+    results = {}
+    for pipeline in (True, False):
+        ctx.set_pipeline(pipeline)
+        ctx.resize_rays(n)
+        for k in range(5):
+            computation(k, leave_dirty=(k == 2))
+        ctx.sync()
+        results[pipeline] = dict(sum=ctx.read_photon_map(0), max=ctx.read_photon_map(1), dose=ctx.read_dosage(),
+                                 color=ctx.read_color(), seed=ctx.seed)
+    ctx.set_pipeline(True)
+    assert same(results[True], results[False])
+    # the oracle for the last computation (k = 4)
+    pm = np.zeros(oscene.T, dtype=np.float64)
+    mm = np.zeros(oscene.T, dtype=np.float64)
+    seed = 4
+    for li in (4, 9, 11):
+        rays, seed = orc.generate(0, n, lps[li], oroute["lightLength"], seed)
+        temp = np.zeros(oscene.T, dtype=np.int32)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        orc.accumulate(pm, mm, temp, 14.0)
+    assert np.array_equal(results[True]["sum"], pm) and np.array_equal(results[True]["max"], mm)
