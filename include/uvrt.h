@@ -160,7 +160,11 @@ int uvrt_read_photon_map(uvrt_ctx* ctx, int32_t which_map, double* out, int32_t 
                          int32_t count);
 /* raw device pointers of the per-triangle arrays, for zero-copy wrapping (e.g. as torch
  * tensors handed to an RCCL collective).  which: 0 photonMap f64[T], 1 maxPhotonMap f64[T],
- * 2 tempPhotonMap i32[T], 3 dosageMap f32[T], 4 colour f32[9T]. */
+ * 2 tempPhotonMap i32[T], 3 dosageMap f32[T], 4 colour f32[9T].
+ * The call is also the ordering point for external work on these arrays: it orders the context's
+ * stream after every outstanding launch (with launch pipelining some sit on the library's second
+ * stream) and makes the library's next work on the arrays wait for whatever the caller enqueues on
+ * the context's stream before its next uvrt call.  Call it before EVERY external use, not once. */
 int uvrt_device_ptr(uvrt_ctx* ctx, int32_t which, void** ptr, int64_t* bytes);
 /* copy one of those arrays to (to_ctx = 0) or from (to_ctx = 1) an external device buffer of the
  * same size, on the context's stream (staging for collectives when zero-copy wrapping is not

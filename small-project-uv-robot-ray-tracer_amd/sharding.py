@@ -111,6 +111,12 @@ class MapReducer:
             self.staged = True
 
     def __call__(self):
+        # uvrt_device_ptr orders the context's stream after all outstanding launches (they may sit
+        # on the library's second stream, include/uvrt.h uvrt_set_pipeline) and makes the next
+        # accumulate / Shade wait for what is enqueued here: call it before EVERY external use of the
+        # maps, not only once when the tensors are made
+        self.ctx.device_ptr(0)
+        self.ctx.device_ptr(1)
         if self.staged:
             self.ctx.copy_device(0, self.sum_t.data_ptr(), False)
             self.ctx.copy_device(1, self.max_t.data_ptr(), False)

@@ -30,9 +30,9 @@ def bench(args, ranks=1, port=29530):
 
 def test_two_rank_rehearsal_matches_single_rank():
     common = ["--photons", "300000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
-    one = bench(common + ["--waves", "4"])
-    weak = bench(common + ["--waves", "2"], ranks=2, port=29531)                 # 2 ranks x 2 waves = 4 launches
-    strong = bench(common + ["--waves", "4", "--scaling", "strong"], ranks=2, port=29532)
+    one = bench(common + ["--waves", "6"])
+    weak = bench(common + ["--waves", "3"], ranks=2, port=29531)                 # 2 ranks x 3 waves = 6 launches
+    strong = bench(common + ["--waves", "6", "--scaling", "strong"], ranks=2, port=29532)
     assert weak["n_gpus"] == strong["n_gpus"] == 2 and weak["scaling"] == "weak" and strong["scaling"] == "strong"
     assert weak["multi_gpu_check"]["dose_identical_on_all_ranks"]
     assert strong["multi_gpu_check"]["dose_identical_on_all_ranks"]

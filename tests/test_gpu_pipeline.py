@@ -196,3 +196,55 @@ def test_back_to_back_computations_without_host_sync(ctx, orc, oscene, oroute):
         orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
         orc.accumulate(pm, mm, temp, 14.0)
     assert np.array_equal(results[True]["sum"], pm) and np.array_equal(results[True]["max"], mm)
+
+
+def test_external_work_on_the_maps_is_ordered_after_all_lanes(pkg, orc, oscene, oroute):
+    """What sharding.MapReducer relies on: after uvrt_device_ptr, work enqueued on the context's
+    stream (here: a torch copy of photonMap on the torch stream the context runs on) sees every
+    launch, including those still running on the library's second stream; and an accumulate that
+    follows waits for that external work (the copy is overwritten with a marker first)."""
+    import torch
+    from uvrt_amd import sharding
+    lps = positions(orc, oscene, oroute)
+    n = 400000
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    c = pkg.capi.Ctx(0)
+    try:
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        c.set_stream(stream.cuda_stream)
+        c.resize_rays(n)
+        with torch.cuda.stream(stream):
+            reducer = sharding.MapReducer(c, dev)
+            c.reset(False)
+            c.seed = 0
+            for li in (0, 3, 6):                      # three launches: the last sits on a side lane
+                c.generate(lps[li], oroute["lightLength"], 0, n)
+                c.extend(n)
+                c.accumulate(2.0)
+            reducer()                                  # world size 1: no collective, but the ordering call
+            snap = reducer.sum_t.clone()               # external work on the context's stream
+            reducer.sum_t.mul_(2.0)                    # ... that also MODIFIES the map
+            c.generate(lps[9], oroute["lightLength"], 0, n)
+            c.extend(n)
+            c.accumulate(2.0)                          # must come after the doubling
+            c.sync()
+            final = c.read_photon_map(0)
+        torch.cuda.synchronize()
+        pm = np.zeros(oscene.T, dtype=np.float64)
+        mm = np.zeros(oscene.T, dtype=np.float64)
+        seed = 0
+        for li in (0, 3, 6):
+            rays, seed = orc.generate(0, n, lps[li], oroute["lightLength"], seed)
+            temp = np.zeros(oscene.T, dtype=np.int32)
+            orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+            orc.accumulate(pm, mm, temp, 2.0)
+        assert np.array_equal(snap.cpu().numpy(), pm)
+        rays, seed = orc.generate(0, n, lps[9], oroute["lightLength"], seed)
+        temp = np.zeros(oscene.T, dtype=np.int32)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        want = pm * 2.0
+        orc.accumulate(want, mm, temp, 2.0)
+        assert np.array_equal(final, want)
+    finally:
+        c.close()
