@@ -56,13 +56,14 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("UVRT_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(glb, route_xml, waves, photons):
+def cpu_baseline(glb, route_xml, waves, photons, flavour=0):
     """The oracle (CPU restatement of the reference kernels, OpenMP on all host cores) timed on
     the same workload: `waves` launches of `photons` photons from lamp 0.  Also returns the
     traversal census that prices the algorithmic bytes per ray."""
     import __graft_entry__ as g
     orc = g.load_oracle()
     import numpy as np
+    orc.set_flavour(flavour)
     s = orc.Scene(glb)
     r = orc.load_route(route_xml)
     cores = host_cores()
@@ -126,6 +127,9 @@ def main():
                          "('pixel tiles'), int32 count all-reduce per launch")
     ap.add_argument("--sort-bits", type=int, default=None)
     ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--flavour", type=int, default=0, choices=[0, 1],
+                    help="arithmetic flavour of IntersectTri (include/uvrt.h uvrt_set_flavour): 0 = canonical strict "
+                         "(SURVEY 8c), 1 = the fused cross/dot ROCm's OpenCL gives the reference's extend.cl on gfx950")
     args = ap.parse_args()
 
     import numpy as np
@@ -181,6 +185,7 @@ def main():
         rt.ctx.set_variant(args.variant)
     if args.no_pipeline:
         rt.ctx.set_pipeline(False)
+    rt.ctx.set_flavour(args.flavour)
     reducer = sharding.MapReducer(rt.ctx, device) if (world > 1 and not strong) else None
 
     if strong:
@@ -242,6 +247,21 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     rt.Sync()                                  # surfaces a traversal-stack overflow, if any
+    # the result of the TIMED region itself (the last of its steps), read before anything else runs
+    import zlib
+    dose_timed = rt.read_dosage()
+    crc_timed = "%08x" % zlib.crc32(dose_timed.tobytes())
+    # one computation on its own, bracketed by syncs (the reference syncs every iteration,
+    # myapp.cpp:165; `value` is the steady-state rate of back-to-back computations)
+    single_ms = []
+    for _ in range(max(1, min(5, args.steps))):
+        sync_all()
+        t1 = time.perf_counter()
+        step()
+        sync_all()
+        single_ms.append((time.perf_counter() - t1) * 1e3)
+    single_ms.sort()
+    single_ms = single_ms[len(single_ms) // 2]
     # timing pass for the roofline: the same step, launches not overlapped, events around extend
     timing_steps = max(1, min(3, args.steps))
     rt.ctx.set_pipeline(False)
@@ -278,11 +298,12 @@ def main():
         cpu = None
         census = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu, census, ref_dose = cpu_baseline(glb, route_xml, args.waves, args.photons)
-            same = np.array_equal(dose.view(np.uint32), ref_dose.view(np.uint32))
+            cpu, census, ref_dose = cpu_baseline(glb, route_xml, args.waves, args.photons, args.flavour)
+            same = np.array_equal(dose_timed.view(np.uint32), ref_dose.view(np.uint32))
             cpu["gpu_dose_bit_identical"] = bool(same)
+            cpu["checked"] = "dose read right after the timed (pipelined) steps, before the timing pass"
             if not same:
-                print("WARNING: GPU dose differs from the oracle", file=sys.stderr)
+                raise SystemExit("bench: the dose of the timed region differs from the oracle's")
         if census is None and os.path.exists(census_path()) and args.photons == PHOTONS:
             census = json.load(open(census_path()))["per_launch_avg"]
             n_census = 1
@@ -299,7 +320,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "extend_pmc.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            roof = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": "k_extend6<2,false,true,%s>" % ("true" if args.flavour else "false"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
                     "rays_per_launch": rt.photonsPerLight, "avg_launch_ms": round(avg_ms, 4),
@@ -323,8 +344,15 @@ def main():
                        "parallelism": "launch-sharded x%d" % world + (" (REHEARSAL: ranks share a GPU, gloo)" if rehearsal else "")},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        import zlib
-        out["dose_crc32"] = "%08x" % zlib.crc32(dose.tobytes())
+        out["dose_crc32"] = crc_timed
+        out["dose_crc32_after_timing_pass"] = "%08x" % zlib.crc32(dose.tobytes())
+        if out["dose_crc32"] != out["dose_crc32_after_timing_pass"]:
+            raise SystemExit("bench: pipelined and one-stream passes disagree (%s vs %s)"
+                             % (out["dose_crc32"], out["dose_crc32_after_timing_pass"]))
+        out["value_is"] = "steady-state throughput of back-to-back computations (no sync between steps)"
+        out["single_computation"] = {"ms": round(single_ms, 4), "mray_s": round(rays_per_step / single_ms / 1e3, 1),
+                                     "note": "one step bracketed by device syncs, median of %d" % max(1, min(5, args.steps))}
+        out["config"]["flavour"] = args.flavour
         if world > 1:
             out["multi_gpu_check"] = {"dose_identical_on_all_ranks": ranks_agree, "photons_deposited": total_hits,
                                       "photons_traced": rays_per_step}

@@ -60,6 +60,8 @@ def lib():
         L.orc_seed_of.argtypes = [C.c_int32, fp, C.c_uint32]
         L.orc_generate_one.restype = C.c_uint32
         L.orc_generate_one.argtypes = [C.c_void_p, C.c_int32, fp, C.c_float, C.c_uint32]
+        L.orc_generate_fixed_seed.restype = C.c_uint32
+        L.orc_generate_fixed_seed.argtypes = [C.c_void_p, C.c_int64, C.c_int64, fp, C.c_float, C.c_uint32, C.c_int]
         L.orc_generate.restype = None
         L.orc_generate.argtypes = [C.c_void_p, C.c_int64, C.c_int64, fp, C.c_float,
                                    C.POINTER(C.c_uint32)]
@@ -202,6 +204,15 @@ def generate(first, n, lp, lightLength, SEED):
     lib().orc_generate(_p(rays), int(first), int(n), _f3(lp), float(np.float32(lightLength)),
                        C.byref(s))
     return rays, int(s.value)
+
+
+def generate_fixed_seed(first, n, lp, lightLength, SEED, saturate=False):
+    """Every work-item reads the same SEED (uvrt_oracle.h orc_generate_fixed_seed).  Returns
+    (rays[n], final RNG state of gid 0 or 0)."""
+    rays = np.zeros(n, dtype=RAY_DT)
+    s0 = lib().orc_generate_fixed_seed(_p(rays), int(first), int(n), _f3(lp), float(np.float32(lightLength)),
+                                       int(SEED), int(bool(saturate)))
+    return rays, int(s0)
 
 
 def set_flavour(flavour):
@@ -356,6 +367,9 @@ def refgpu():
                                       C.POINTER(C.c_double)]
         L.refgpu_shade.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+        L.refgpu_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.refgpu_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32]
+        L.refgpu_compute_dosage.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
         if L.refgpu_load(os.fsencode(d)) != 0:
             raise RuntimeError("refgpu_load: " + L.refgpu_last_error().decode())
         _REFGPU = L
@@ -373,6 +387,49 @@ def refgpu_extend(rays, tris, nodes, triIdx, reps=1):
                        _p(counts), C.byref(ms), int(reps)) != 0:
         raise RuntimeError("refgpu_extend: " + L.refgpu_last_error().decode())
     return counts, float(ms.value)
+
+
+def refgpu_reload():
+    """Fresh modules: program-scope SEED = 0 again (generate.cl:6), as after RayTracer::Init."""
+    if refgpu().refgpu_reload() != 0:
+        raise RuntimeError("refgpu_reload: " + refgpu().refgpu_last_error().decode())
+
+
+def refgpu_generate(n, lp, lightLength):
+    """generate.cl:render of the reference on the GPU over n work-items (n % 256 == 0), with whatever
+    SEED the loaded module holds.  Returns (rays, kernel_ms)."""
+    L = refgpu()
+    assert n % 256 == 0
+    rays = np.zeros(n, dtype=RAY_DT)
+    ms = C.c_double()
+    if L.refgpu_generate(_p(rays), int(n), _f3(lp), float(np.float32(lightLength)), C.byref(ms)) != 0:
+        raise RuntimeError("refgpu_generate: " + L.refgpu_last_error().decode())
+    return rays, float(ms.value)
+
+
+def refgpu_reset(photonMap, maxPhotonMap, temp, color, resetColor):
+    """reset.cl:render of the reference on the GPU; the arrays are updated in place."""
+    L = refgpu()
+    assert color.dtype == np.float32 and color.size == 9 * temp.size
+    if L.refgpu_reset(_p(photonMap), _p(maxPhotonMap), _p(temp), _p(color), temp.size, int(bool(resetColor))) != 0:
+        raise RuntimeError("refgpu_reset: " + L.refgpu_last_error().decode())
+
+
+def refgpu_accumulate(photonMap, maxPhotonMap, temp, timeStep):
+    """accumulate.cl:render of the reference on the GPU; the arrays are updated in place."""
+    L = refgpu()
+    if L.refgpu_accumulate(_p(photonMap), _p(maxPhotonMap), _p(temp), float(np.float32(timeStep)), temp.size) != 0:
+        raise RuntimeError("refgpu_accumulate: " + L.refgpu_last_error().decode())
+
+
+def refgpu_compute_dosage(pmap, tris, photonsPerLight, scaledPower):
+    """shade.cl:computeDosage of the reference on the GPU."""
+    L = refgpu()
+    dose = np.zeros(pmap.size, dtype=np.float32)
+    if L.refgpu_compute_dosage(_p(pmap), _p(tris), pmap.size, int(photonsPerLight),
+                               float(np.float32(scaledPower)), _p(dose)) != 0:
+        raise RuntimeError("refgpu_compute_dosage: " + L.refgpu_last_error().decode())
+    return dose
 
 
 def refgpu_generate_ms(n, lp, lightLength):

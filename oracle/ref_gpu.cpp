@@ -13,7 +13,11 @@
 // (template.cpp:1192), which is the canonical "strict" flavour of SURVEY.md 8c -- except that
 // AMD's OpenCL library implements dot()/cross() with fused multiply-adds, so a tiny fraction of
 // rays can round differently from the x86 strict build (measured by the tests, not assumed).
-// generate.cl is racy on a GPU (SEED): it is only timed, never compared.
+// generate.cl is racy on a GPU (SEED), but the race has only two outcomes per work-item:
+// it read SEED before or after work-item 0 stored its final RNG state (generate.cl:13,39).  On a
+// freshly loaded module (SEED = 0, generate.cl:6) every reference ray must therefore equal the
+// oracle's ray under SEED = 0 or SEED = SEED_1 -- that is how tests/test_gpu_reference_kernels.py
+// pins generate (refgpu_reload gives the fresh module).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -39,9 +43,12 @@ extern "C" {
 
 const char* refgpu_last_error(void) { return g_err.c_str(); }
 
+static std::string g_dir;
+
 int refgpu_load(const char* dir)
 {
     if (g_loaded) return 0;
+    g_dir = dir;
     const char* names[5] = {"generate", "extend", "accumulate", "reset", "shade"};
     for (int i = 0; i < 5; ++i) {
         std::string path = std::string(dir) + "/ref_" + names[i] + ".co";
@@ -55,6 +62,18 @@ int refgpu_load(const char* dir)
     TRY(hipModuleGetFunction(&g_dosage_to_color, g_mod[4], "dosageToColor"));
     g_loaded = true;
     return 0;
+}
+
+// Unload and reload every code object: program-scope variables start from their initialisers again,
+// i.e. SEED = 0 like after RayTracer::Init's `new Kernel("cl/generate.cl", "render")` (raytracer.cpp:17).
+int refgpu_reload(void)
+{
+    if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
+    TRY(hipDeviceSynchronize());
+    for (int i = 0; i < 5; ++i) TRY(hipModuleUnload(g_mod[i]));
+    g_loaded = false;
+    const std::string d = g_dir;
+    return refgpu_load(d.c_str());
 }
 
 static int launch1d(hipFunction_t f, size_t count, void** args)
@@ -115,7 +134,7 @@ int refgpu_extend(void* rays32, int64_t n, const void* tris64, int32_t T, const 
     return 0;
 }
 
-// generate.cl:render (timing only; SEED is racy on a GPU).  rays32_out may be NULL.
+// generate.cl:render over n work-items (n % 256 == 0).  rays32_out may be NULL (timing only).
 int refgpu_generate(void* rays32_out, int64_t n, const float light_pos[3], float light_length, double* ms)
 {
     if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
@@ -166,6 +185,68 @@ int refgpu_shade(double* photon_map, double* max_map, int32_t* counts, float tim
     TRY(hipMemcpy(dosage_out, d_dose, (size_t)T * 4, hipMemcpyDeviceToHost));
     TRY(hipMemcpy(color_out9, d_col, (size_t)T * 36, hipMemcpyDeviceToHost));
     hipFree(d_pm); hipFree(d_mm); hipFree(d_c); hipFree(d_t); hipFree(d_dose); hipFree(d_col);
+    return 0;
+}
+
+// reset.cl:render over T triangles on host arrays (updated in place); color9 = 9 floats per triangle
+int refgpu_reset(double* photon_map, double* max_map, int32_t* counts, float* color9, int32_t T, int32_t reset_color)
+{
+    if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
+    const size_t Tp = ((size_t)T + 255) / 256 * 256;      // whole work-groups; the padding is scratch
+    void *d_pm, *d_mm, *d_c, *d_col;
+    TRY(hipMalloc(&d_pm, Tp * 8)); TRY(hipMalloc(&d_mm, Tp * 8)); TRY(hipMalloc(&d_c, Tp * 4)); TRY(hipMalloc(&d_col, Tp * 36));
+    TRY(hipMemcpy(d_pm, photon_map, (size_t)T * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_mm, max_map, (size_t)T * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_c, counts, (size_t)T * 4, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_col, color9, (size_t)T * 36, hipMemcpyHostToDevice));
+    void* a[5] = {&d_pm, &d_mm, &d_c, &d_col, &reset_color};
+    if (launch1d(g_reset, Tp, a)) return -1;
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(photon_map, d_pm, (size_t)T * 8, hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(max_map, d_mm, (size_t)T * 8, hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(counts, d_c, (size_t)T * 4, hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(color9, d_col, (size_t)T * 36, hipMemcpyDeviceToHost));
+    hipFree(d_pm); hipFree(d_mm); hipFree(d_c); hipFree(d_col);
+    return 0;
+}
+
+// accumulate.cl:render alone (raytracer.cpp:84-85), host arrays updated in place
+int refgpu_accumulate(double* photon_map, double* max_map, int32_t* counts, float time_step, int32_t T)
+{
+    if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
+    const size_t Tp = ((size_t)T + 255) / 256 * 256;
+    void *d_pm, *d_mm, *d_c;
+    TRY(hipMalloc(&d_pm, Tp * 8)); TRY(hipMalloc(&d_mm, Tp * 8)); TRY(hipMalloc(&d_c, Tp * 4));
+    TRY(hipMemset(d_pm, 0, Tp * 8)); TRY(hipMemset(d_mm, 0, Tp * 8)); TRY(hipMemset(d_c, 0, Tp * 4));
+    TRY(hipMemcpy(d_pm, photon_map, (size_t)T * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_mm, max_map, (size_t)T * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_c, counts, (size_t)T * 4, hipMemcpyHostToDevice));
+    void* a[4] = {&d_pm, &d_mm, &d_c, &time_step};
+    if (launch1d(g_accumulate, Tp, a)) return -1;
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(photon_map, d_pm, (size_t)T * 8, hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(max_map, d_mm, (size_t)T * 8, hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(counts, d_c, (size_t)T * 4, hipMemcpyDeviceToHost));
+    hipFree(d_pm); hipFree(d_mm); hipFree(d_c);
+    return 0;
+}
+
+// shade.cl:computeDosage alone (raytracer.cpp:96-118) on a host map
+int refgpu_compute_dosage(const double* map, const void* tris64, int32_t T, int32_t photons_per_light,
+                          float scaled_power, float* dosage_out)
+{
+    if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
+    const size_t Tp = ((size_t)T + 255) / 256 * 256;
+    void *d_m, *d_t, *d_dose;
+    TRY(hipMalloc(&d_m, Tp * 8)); TRY(hipMalloc(&d_t, Tp * 64)); TRY(hipMalloc(&d_dose, Tp * 4));
+    TRY(hipMemset(d_m, 0, Tp * 8)); TRY(hipMemset(d_t, 0, Tp * 64));
+    TRY(hipMemcpy(d_m, map, (size_t)T * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_t, tris64, (size_t)T * 64, hipMemcpyHostToDevice));
+    void* a[5] = {&d_m, &d_dose, &d_t, &photons_per_light, &scaled_power};
+    if (launch1d(g_compute_dosage, Tp, a)) return -1;
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(dosage_out, d_dose, (size_t)T * 4, hipMemcpyDeviceToHost));
+    hipFree(d_m); hipFree(d_t); hipFree(d_dose);
     return 0;
 }
 

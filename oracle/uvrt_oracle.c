@@ -57,10 +57,10 @@ uint32_t orc_seed_of(int32_t tid, const float lp[3], uint32_t SEED)
     return (uint32_t)(int64_t)acc;
 }
 
-uint32_t orc_generate_one(orc_ray* out, int32_t tid, const float lp[3], float lightLength,
-                          uint32_t SEED)
+static uint32_t generate_from_hash_input(orc_ray* out, uint32_t hash_input, const float lp[3],
+                                         float lightLength)
 {
-    uint32_t seed = orc_wang_hash(orc_seed_of(tid, lp, SEED));          /* :13 */
+    uint32_t seed = orc_wang_hash(hash_input);                           /* :13 */
 
     out->origx = lp[0];                                                  /* :16-19 */
     out->origy = lp[1] + orc_random_float(&seed) * lightLength;
@@ -86,6 +86,39 @@ uint32_t orc_generate_one(orc_ray* out, int32_t tid, const float lp[3], float li
     out->dist = 1e30f;
     out->triID = 0;
     return seed;                                                         /* :39 (tid 0) */
+}
+
+uint32_t orc_generate_one(orc_ray* out, int32_t tid, const float lp[3], float lightLength,
+                          uint32_t SEED)
+{
+    return generate_from_hash_input(out, orc_seed_of(tid, lp, SEED), lp, lightLength);
+}
+
+/* Test helper for pinning generate.cl against the reference's own kernel running on a GPU, where
+ * SEED is racy (generate.cl:6,13,39): EVERY work-item of [first, first+n) reads the same SEED.
+ * saturate != 0 converts a negative seed sum to 0 instead of going through int64: float -> uint of
+ * a negative value is undefined in OpenCL C, and v_cvt_u32_f32 (what the reference's kernel becomes
+ * on gfx950) saturates.  Returns the final RNG state of gid 0 (what it would store in SEED), or 0
+ * when gid 0 is not in the range. */
+uint32_t orc_generate_fixed_seed(orc_ray* rays, int64_t first, int64_t n, const float lp[3],
+                                 float lightLength, uint32_t SEED, int saturate)
+{
+    uint32_t seed0 = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t tid = (int32_t)(first + i);
+        uint32_t h = orc_seed_of(tid, lp, SEED);
+        if (saturate) {
+            float acc = (float)(tid * 17 + 1);
+            acc = acc + lp[0] * 13.0f;
+            acc = acc + lp[1] * 7.0f;
+            acc = acc + lp[2] * 11.0f;
+            acc = acc + (float)(SEED >> 15);
+            if (acc < 0.0f) h = 0u;
+        }
+        const uint32_t fin = generate_from_hash_input(&rays[i], h, lp, lightLength);
+        if (first + i == 0) seed0 = fin;
+    }
+    return seed0;
 }
 
 void orc_generate(orc_ray* rays, int64_t first, int64_t n, const float lp[3],

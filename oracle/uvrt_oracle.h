@@ -83,6 +83,12 @@ uint32_t orc_generate_one(orc_ray* out, int32_t tid, const float lightPos[3], fl
 void orc_generate(orc_ray* rays, int64_t first, int64_t n, const float lightPos[3],
                   float lightLength, uint32_t* SEED);
 
+/* Test helper: every work-item of [first, first+n) reads the SAME SEED (one outcome of the
+ * reference's SEED race on a GPU, generate.cl:6,13,39); saturate != 0: a negative seed sum becomes 0
+ * (v_cvt_u32_f32) instead of taking the int64 route.  Returns gid 0's final RNG state (or 0). */
+uint32_t orc_generate_fixed_seed(orc_ray* rays, int64_t first, int64_t n, const float lightPos[3],
+                                 float lightLength, uint32_t SEED, int saturate);
+
 /* Arithmetic flavour of IntersectTri's cross()/dot() (extend.cl:14-24):
  *   0 (default, canonical -- SURVEY.md 8c): unfused, dot = x*x + y*y + z*z, cross = a*b - c*d
  *   1 "ocl-amd": what the reference's extend.cl becomes when built with ROCm's OpenCL device

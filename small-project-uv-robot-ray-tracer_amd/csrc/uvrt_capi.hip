@@ -246,7 +246,7 @@ void split_bits(int bits, int& bphi, int& by, int& bo)
 bool variant_is_v6(const uvrt_ctx* c)
 {
     const bool fits = (size_t)c->npairs + (size_t)c->T < ((size_t)1 << 26);   // 32-bit record offsets
-    if (c->variant == 0) return fits && c->flavour == 0;
+    if (c->variant == 0) return fits;
     return c->variant >= 400 && c->variant < 900;
 }
 
@@ -713,8 +713,8 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         (c->variant >= 500 && c->variant < 600))
         p.force_exact = 1;
     p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
-    if (c->flavour != 0 && c->variant != 0 && c->variant != 90)
-        return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by the default and the v4 kernel (variants 0, 90) only");
+    if (c->flavour != 0 && !v6 && c->variant != 0 && c->variant != 90)
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by extend v6 and the v4 kernel (variant 90) only");
     if (c->variant >= 400 && c->variant < 900 && (size_t)c->npairs + (size_t)c->T >= ((size_t)1 << 26))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: scene too large for extend v6's record numbering");
     if (!v6 && !c->recip_valid) {

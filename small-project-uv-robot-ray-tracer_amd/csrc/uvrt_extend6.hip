@@ -101,28 +101,43 @@ __device__ __forceinline__ float rcp_exact(float a)
     return __builtin_fmaf(e, y0, y0);
 }
 
-// extend.cl:6-27 on a leaf record (v0, e1 = v1 - v0, e2 = v2 - v0, id in v0.w)
+// extend.cl:6-27 on a leaf record (v0, e1 = v1 - v0, e2 = v2 - v0, id in v0.w).
+// OCL = the "ocl-amd" flavour (include/uvrt.h uvrt_set_flavour): cross() and dot() in the fused forms
+// ROCm's OpenCL device library gives the reference's extend.cl on gfx950 (read off the disassembly of
+// oracle/_ref/ref_extend.co): cross(a, b).x = fma(a.y, b.z, -(a.z * b.y)), dot(a, b) = fma(a.z, b.z,
+// fma(a.y, b.y, a.x * b.x)); everything else as extend.cl writes it.
+template <bool OCL>
+__device__ __forceinline__ float cross6(float ay, float bz, float az, float by)
+{
+    return OCL ? __builtin_fmaf(ay, bz, -(az * by)) : ay * bz - az * by;
+}
+template <bool OCL>
+__device__ __forceinline__ float dot6(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return OCL ? __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx)) : ax * bx + ay * by + az * bz;
+}
+template <bool OCL>
 __device__ __forceinline__ void tri6(float ox, float oy, float oz, float dx, float dy, float dz, float& dist,
                                      uint32_t& triID, const float4 v0, const float4 e1, const float4 e2,
                                      bool exact)
 {
-    const float hx = dy * e2.z - dz * e2.y;
-    const float hy = dz * e2.x - dx * e2.z;
-    const float hz = dx * e2.y - dy * e2.x;
-    const float a = e1.x * hx + e1.y * hy + e1.z * hz;
+    const float hx = cross6<OCL>(dy, e2.z, dz, e2.y);
+    const float hy = cross6<OCL>(dz, e2.x, dx, e2.z);
+    const float hz = cross6<OCL>(dx, e2.y, dy, e2.x);
+    const float a = dot6<OCL>(e1.x, e1.y, e1.z, hx, hy, hz);
     if (fabsf(a) < 0.00001f) return;
     float f;
     if (exact) f = 1.0f / a;         // wave-uniform
     else f = rcp_exact(a);
     const float sx = ox - v0.x, sy = oy - v0.y, sz = oz - v0.z;
-    const float u = f * (sx * hx + sy * hy + sz * hz);
+    const float u = f * dot6<OCL>(sx, sy, sz, hx, hy, hz);
     if ((u < 0) | (u > 1)) return;
-    const float qx = sy * e1.z - sz * e1.y;
-    const float qy = sz * e1.x - sx * e1.z;
-    const float qz = sx * e1.y - sy * e1.x;
-    const float v = f * (dx * qx + dy * qy + dz * qz);
+    const float qx = cross6<OCL>(sy, e1.z, sz, e1.y);
+    const float qy = cross6<OCL>(sz, e1.x, sx, e1.z);
+    const float qz = cross6<OCL>(sx, e1.y, sy, e1.x);
+    const float v = f * dot6<OCL>(dx, dy, dz, qx, qy, qz);
     if ((v < 0) | (u + v > 1)) return;
-    const float tt = f * (e2.x * qx + e2.y * qy + e2.z * qz);
+    const float tt = f * dot6<OCL>(e2.x, e2.y, e2.z, qx, qy, qz);
     if (tt > 0.0001f && tt < dist) {
         dist = tt;
         triID = __float_as_uint(v0.w);
@@ -165,7 +180,7 @@ __device__ __forceinline__ uint32_t* ovf_ptr(const ExtendParams& p)
 
 // `exact` is wave-uniform: the record fetch and the descend / push / pop logic are common, only the
 // arithmetic of the box and triangle tests differs.
-template <bool TOP>
+template <bool TOP, bool OCL>
 __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t stack_base,
                                       const float4* s_top, uint32_t top_pairs, bool leaf_trip, bool exact,
                                       unsigned long long m_act /* lanes holding a ray */)
@@ -225,12 +240,12 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         const uint32_t first = idx - (uint32_t)p.npairs;
         if (count == 15u) count = p.scene.leaf_count[first];
         float dist = L.po.y;
-        tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+        tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
              make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
              make_float4(w2.x, w2.y, w2.z, w2.w), exact);
         for (uint32_t i = 1; i < count; ++i) {
             const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
-            tri6(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
+            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
         }
         L.po.y = dist;
     }
@@ -272,7 +287,7 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
     }
 }
 
-template <int LEAFP, bool RECORD, bool TOP>
+template <int LEAFP, bool RECORD, bool TOP, bool OCL>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
     __shared__ uint32_t s_stack[PS6][256];                          // 8 KB
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __builtin_amdgcn_ballot_w64(L.cur < REF_LEAF_BIT) == 0;
             ++trip;
         }
-        step6<TOP>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0, act);
+        step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0, act);
     }
     // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
     if (RECORD && live && p.hits) {
@@ -421,10 +436,11 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
     if (p.npairs > 0 && !p.recs_prepared)
         hipLaunchKernelGGL(k_prepare_launch6, dim3((unsigned)((p.npairs + 255) / 256)), dim3(256), 0, s,
                            p.scene.pairs, (float4*)p.recs, p.ox, p.oz, p.npairs, p.perm);
+#define UVRT_L6K(LP, REC, TOP, OCL) hipLaunchKernelGGL((k_extend6<LP, REC, TOP, OCL>), dim3(grid), dim3(256), 0, s, p)
 #define UVRT_L6(LP, TOP)                                                                             \
     do {                                                                                             \
-        if (p.hits) hipLaunchKernelGGL((k_extend6<LP, true, TOP>), dim3(grid), dim3(256), 0, s, p);    \
-        else hipLaunchKernelGGL((k_extend6<LP, false, TOP>), dim3(grid), dim3(256), 0, s, p);         \
+        if (p.flavour) { if (p.hits) UVRT_L6K(LP, true, TOP, true); else UVRT_L6K(LP, false, TOP, true); }   \
+        else { if (p.hits) UVRT_L6K(LP, true, TOP, false); else UVRT_L6K(LP, false, TOP, false); }          \
     } while (0)
     switch (code & 7) {
         case 0: UVRT_L6(1, true); break;
@@ -436,6 +452,7 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
         case 6: UVRT_L6(3, false); break;
         default: UVRT_L6(4, false); break;
     }
+#undef UVRT_L6K
 #undef UVRT_L6
     return true;
 }

@@ -77,27 +77,45 @@ def test_extend_hits_and_counts_bit_exact(ctx, orc, oscene, oroute, sort_bits):
 def test_every_extend_variant_is_bit_exact(ctx, orc, oscene, oroute, variant):
     """All kernel variants (v1 per-ray, persistent with different refill thresholds / grid sizes,
     LDS-staged cooperative fetch) give the same bits: layout and scheduling never change results."""
+    _variant_case(ctx, orc, oscene, oroute, variant, 0)
+
+
+@pytest.mark.parametrize("variant", [0, 400, 401, 403, 404, 405, 421, 500, 505, 601, 801])
+def test_every_v6_variant_is_bit_exact_in_the_ocl_flavour(ctx, orc, oscene, oroute, variant):
+    """flavour 1 (fused cross/dot of ROCm's OpenCL library, uvrt_set_flavour) on the default kernel and
+    its variants (leaf period, LDS top cache, grid, refill threshold, IEEE divisions) against the
+    oracle in the same flavour."""
+    _variant_case(ctx, orc, oscene, oroute, variant, 1)
+
+
+def _variant_case(ctx, orc, oscene, oroute, variant, flavour):
     n = 300000
     lp = lamp_pos(orc, oscene, oroute, 5)
     ctx.set_variant(variant)
+    ctx.set_flavour(flavour)
     ctx.set_sort_bits(0)
     ctx.set_record_hits(True)
-    ctx.resize_rays(n)
-    ctx.reset(False)
-    ctx.seed = 7
-    ctx.generate(lp, oroute["lightLength"], 0, n)
-    ctx.extend(n)
-    ctx.sync()
-    got = ctx.read_rays(0, n)
-    counts = ctx.read_counts()
-    rays, _ = orc.generate(0, n, lp, oroute["lightLength"], 7)
-    temp = np.zeros(oscene.T, dtype=np.int32)
-    orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
-    assert np.array_equal(bits(got["dist"]), bits(rays["dist"]))
-    assert np.array_equal(got["triID"], rays["triID"])
-    assert np.array_equal(counts, temp)
-    ctx.set_variant(0)
-    ctx.set_record_hits(False)
+    orc.set_flavour(flavour)
+    try:
+        ctx.resize_rays(n)
+        ctx.reset(False)
+        ctx.seed = 7
+        ctx.generate(lp, oroute["lightLength"], 0, n)
+        ctx.extend(n)
+        ctx.sync()
+        got = ctx.read_rays(0, n)
+        counts = ctx.read_counts()
+        rays, _ = orc.generate(0, n, lp, oroute["lightLength"], 7)
+        temp = np.zeros(oscene.T, dtype=np.int32)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        assert np.array_equal(bits(got["dist"]), bits(rays["dist"]))
+        assert np.array_equal(got["triID"], rays["triID"])
+        assert np.array_equal(counts, temp)
+    finally:
+        orc.set_flavour(0)
+        ctx.set_variant(0)
+        ctx.set_flavour(0)
+        ctx.set_record_hits(False)
 
 
 def test_full_iteration_two_lamps_matches_survey_golden(ctx, orc, oscene, oroute):
