@@ -111,6 +111,24 @@ int uvrt_set_seed(uvrt_ctx* ctx, uint32_t seed);
  * order. */
 uint32_t uvrt_seed_next(const float light_pos[3], float light_length, uint32_t seed_prev);
 
+/* Advance the context's SEED as a uvrt_generate at this lamp would, without launching (a rank of a
+ * sharded job skipping a launch that another rank traces). */
+int uvrt_advance_seed(uvrt_ctx* ctx, const float light_pos[3], float light_length);
+
+/* Which outcome of generate.cl's SEED race (generate.cl:6,13,39: every work-item reads the
+ * program-scope SEED, work-item 0 overwrites it at its end) and of its float -> uint conversion of a
+ * negative seed sum (undefined in OpenCL C) the context reproduces:
+ *   0 (default) = the canonical semantics of SURVEY.md 8c: serial work-item order -- work-item 0 reads
+ *     SEED_{k-1}, every other work-item reads SEED_k -- and the conversion through int64 (x86-64);
+ *   1 = "gfx950-ocl": what the reference's generate.cl, compiled unmodified by ROCm's OpenCL compiler,
+ *     does on this GPU (measured, tests/test_gpu_reference_kernels.py): SEED is fetched through the
+ *     scalar cache, so EVERY work-item of launch k reads SEED_{k-1}; v_cvt_u32_f32 turns a negative sum
+ *     into 0.  With uvrt_set_flavour(ctx, 1) the whole pipeline then reproduces the reference's own
+ *     kernel chain running live on the MI355X: counts bit for bit, dose within 1e-4. */
+int uvrt_set_seed_mode(uvrt_ctx* ctx, int32_t mode);
+uint32_t uvrt_seed_next_mode(const float light_pos[3], float light_length, uint32_t seed_prev,
+                             int32_t seed_mode);
+
 /* ---- tuning knobs (results never depend on them) ---- */
 /* bits of the ray-coherence key used to order rays before extend; 0 = trace in gid order
  * (default), -1 = choose from n (about one wavefront of rays per key). */

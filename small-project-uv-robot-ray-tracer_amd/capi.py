@@ -43,6 +43,9 @@ SYMBOLS = [
     ("uvrt_get_seed", C.c_int, [_vp, C.POINTER(_u32)]),
     ("uvrt_set_seed", C.c_int, [_vp, _u32]),
     ("uvrt_seed_next", _u32, [_fp, _f32, _u32]),
+    ("uvrt_advance_seed", C.c_int, [_vp, _fp, _f32]),
+    ("uvrt_set_seed_mode", C.c_int, [_vp, _i32]),
+    ("uvrt_seed_next_mode", _u32, [_fp, _f32, _u32, _i32]),
     ("uvrt_set_sort_bits", C.c_int, [_vp, _i32]),
     ("uvrt_set_record_hits", C.c_int, [_vp, _i32]),
     ("uvrt_set_flavour", C.c_int, [_vp, _i32]),
@@ -91,8 +94,9 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def seed_next(light_pos, light_length, seed_prev):
-    return int(lib().uvrt_seed_next(_f3(light_pos), float(np.float32(light_length)), int(seed_prev)))
+def seed_next(light_pos, light_length, seed_prev, seed_mode=0):
+    return int(lib().uvrt_seed_next_mode(_f3(light_pos), float(np.float32(light_length)), int(seed_prev),
+                                         int(seed_mode)))
 
 
 class Ctx:
@@ -210,6 +214,12 @@ class Ctx:
     @seed.setter
     def seed(self, v):
         self._ck(self._L.uvrt_set_seed(self._h, int(v)))
+
+    def advance_seed(self, light_pos, light_length):
+        self._ck(self._L.uvrt_advance_seed(self._h, _f3(light_pos), float(np.float32(light_length))))
+
+    def set_seed_mode(self, mode):
+        self._ck(self._L.uvrt_set_seed_mode(self._h, int(mode)))
 
     def set_sort_bits(self, bits):
         self._ck(self._L.uvrt_set_sort_bits(self._h, int(bits)))

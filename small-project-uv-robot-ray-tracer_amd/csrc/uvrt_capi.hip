@@ -123,6 +123,7 @@ struct uvrt_ctx {
 
     // generate.cl:6 program-scope SEED
     uint32_t seed = 0;
+    int32_t seed_mode = 0;   // uvrt_set_seed_mode
 
     // knobs
     int32_t sort_bits = 0;   // ray ordering off by default: extend is VALU-bound
@@ -534,13 +535,18 @@ int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
 
 uint32_t uvrt_seed_next(const float lp[3], float light_length, uint32_t seed_prev)
 {
+    return uvrt_seed_next_mode(lp, light_length, seed_prev, 0);
+}
+
+uint32_t uvrt_seed_next_mode(const float lp[3], float light_length, uint32_t seed_prev, int32_t seed_mode)
+{
     // work-item 0 of cl/generate.cl:13-39; the ray itself is not needed, only the RNG state
     float acc = (float)(0 * 17 + 1);
     acc = acc + lp[0] * 13.0f;
     acc = acc + lp[1] * 7.0f;
     acc = acc + lp[2] * 11.0f;
     acc = acc + (float)(seed_prev >> 15);
-    uint32_t seed = host_wang_hash((uint32_t)(int64_t)acc);
+    uint32_t seed = host_wang_hash((seed_mode == 1 && acc < 0.0f) ? 0u : (uint32_t)(int64_t)acc);
     (void)light_length;
     (void)host_random_float(seed);   // origin.y
     (void)host_random_float(seed);   // diry
@@ -564,7 +570,7 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (int rc = set_device(c)) return rc;
 
     const uint32_t seed_prev = c->seed;
-    const uint32_t seed_next = uvrt_seed_next(lp, light_length, seed_prev);
+    const uint32_t seed_next = uvrt_seed_next_mode(lp, light_length, seed_prev, c->seed_mode);
 
     int bits = c->sort_bits < 0 ? auto_sort_bits(n) : c->sort_bits;
     if (bits > 20) bits = 20;
@@ -597,6 +603,7 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     p.n = n;
     p.seed_prev = seed_prev;
     p.seed_next = seed_next;
+    p.seed_mode = c->seed_mode;
     if (bits > 0 && n > 0) {
         const int32_t nbins = 1 << bits;
         if (c->hist_bins < nbins) {
@@ -893,6 +900,20 @@ int uvrt_set_seed(uvrt_ctx* c, uint32_t seed)
 {
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
     c->seed = seed;
+    return UVRT_OK;
+}
+
+int uvrt_advance_seed(uvrt_ctx* c, const float lp[3], float light_length)
+{
+    if (!c || !lp) return fail(UVRT_ERR_INVALID, "uvrt_advance_seed: null argument");
+    c->seed = uvrt_seed_next_mode(lp, light_length, c->seed, c->seed_mode);
+    return UVRT_OK;
+}
+
+int uvrt_set_seed_mode(uvrt_ctx* c, int32_t mode)
+{
+    if (!c || (mode != 0 && mode != 1)) return fail(UVRT_ERR_INVALID, "uvrt_set_seed_mode: mode must be 0 or 1");
+    c->seed_mode = mode;
     return UVRT_OK;
 }
 

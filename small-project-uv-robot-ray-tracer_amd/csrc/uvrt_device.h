@@ -76,6 +76,8 @@ struct GenParams {
     int64_t n;
     uint32_t seed_prev;    // SEED_{k-1}: read by work-item 0
     uint32_t seed_next;    // SEED_k: read by everybody else
+    int32_t seed_mode;     // 0 canonical (above); 1 "gfx950-ocl": every work-item reads SEED_{k-1} and a
+                           // negative seed sum converts to 0 (include/uvrt.h uvrt_set_seed_mode)
     int32_t bits_phi, bits_y, bits_o;
     // extend v6's per-launch records, written by extra workgroups of the same launch (or nullptr)
     const PairRec* prep_pairs;

@@ -104,7 +104,7 @@ __device__ __forceinline__ float rcp_exact(float a)
 // extend.cl:6-27 on a leaf record (v0, e1 = v1 - v0, e2 = v2 - v0, id in v0.w).
 // OCL = the "ocl-amd" flavour (include/uvrt.h uvrt_set_flavour): cross() and dot() in the fused forms
 // ROCm's OpenCL device library gives the reference's extend.cl on gfx950 (read off the disassembly of
-// oracle/_ref/ref_extend.co): cross(a, b).x = fma(a.y, b.z, -(a.z * b.y)), dot(a, b) = fma(a.z, b.z,
+// that kernel as built for gfx950): cross(a, b).x = fma(a.y, b.z, -(a.z * b.y)), dot(a, b) = fma(a.z, b.z,
 // fma(a.y, b.y, a.x * b.x)); everything else as extend.cl writes it.
 template <bool OCL>
 __device__ __forceinline__ float cross6(float ay, float bz, float az, float by)

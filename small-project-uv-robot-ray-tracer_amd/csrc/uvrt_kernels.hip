@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_generate(GenParams p)
     if (i >= p.n) return;
     const int64_t gid = p.first_gid + i;
     const int threadID = (int)gid;                       // generate.cl:11 (int threadID)
-    const uint32_t SEED = gid == 0 ? p.seed_prev : p.seed_next;
+    const uint32_t SEED = (gid == 0 || p.seed_mode == 1) ? p.seed_prev : p.seed_next;
 
     // generate.cl:13 -- f32 adds in source order, then float -> uint through int64
     float acc = (float)(threadID * 17 + 1);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_generate(GenParams p)
     acc = acc + p.ly * 7.0f;
     acc = acc + p.lz * 11.0f;
     acc = acc + (float)(SEED >> 15);
-    uint32_t seed = wang_hash((uint32_t)(int64_t)acc);
+    uint32_t seed = wang_hash((p.seed_mode == 1 && acc < 0.0f) ? 0u : (uint32_t)(int64_t)acc);
 
     const float r0 = random_float(seed);
     const float origy = p.ly + r0 * p.light_length;      // :16

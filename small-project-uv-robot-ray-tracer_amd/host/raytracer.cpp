@@ -175,9 +175,7 @@ void RayTracer::ComputeSingleLightDosageMap(LightPos lightPos, int photonsPerLig
         check(uvrt_accumulate(ctx, lightPos.duration, triangleCount), "accumulate");  // :84-85
     } else {
         // another rank traces this launch; keep generate.cl's program-scope SEED in step
-        uint32_t seed = 0;
-        check(uvrt_get_seed(ctx, &seed), "get_seed");
-        check(uvrt_set_seed(ctx, uvrt_seed_next(lp, lightLength, seed)), "set_seed");
+        check(uvrt_advance_seed(ctx, lp, lightLength), "advance_seed");
     }
     photonMapSize += photonsPerLight;                                   // :87
 }
