@@ -310,25 +310,64 @@ def main():
         else:
             n_census = args.waves
         roof = None
+        avg_ms = ext_ms / max(ext_launches, 1)
+        model_path = os.path.join(ROOT, "profiles", "extend_issue_model.json")
+        if os.path.exists(model_path):
+            # The binding resource, priced with the per-ray instruction / lookup / byte counts of the kernel
+            # (rocprofv3 PMC passes, deterministic per launch: profiles/extend_issue_model.json, made by
+            # tests/tools/issue_model.py) and the issue rates calibrated on this GPU type
+            # (tests/tools/valu_calib.hip, profiles/r02_valu_calibration.txt); the DURATION is this run's.
+            m = json.load(open(model_path))
+            k = m["constants"]
+            pr = m["per_ray"]
+            n_l = float(rt.photonsPerLight)
+            sec = avg_ms * 1e-3
+            scale = n_l / m["rays_per_launch"]
+            simd_cycles = k["simds"] * k["clock_hz"] * sec
+            cu_cycles = k["cus"] * k["clock_hz"] * sec
+            util = {
+                "valu_issue": pr["valu_issue_cycles"] * n_l / simd_cycles,
+                "salu_issue": pr["salu_insts"] * n_l / cu_cycles,
+                "l1_lookup": pr["l1_lane_lookups"] * n_l / (cu_cycles * k["l1_lookups_per_clk_per_cu"]),
+                "hbm": pr["hbm_bytes"] * n_l / sec / k["hbm_peak_bytes_per_s"],
+            }
+            bound = max(util, key=util.get)
+            vc = m["valu_issue_cycles"]
+            roof = {"bound": bound, "kernel": "k_extend6<2,false,true,%s>" % ("true" if args.flavour else "false"),
+                    "achieved": round(pr["valu_issue_cycles"] * n_l / sec / 1e9, 1),
+                    "peak": round(k["simds"] * k["clock_hz"] / 1e9, 1), "unit": "G VALU issue-cycles/s",
+                    "frac": round(util["valu_issue"], 4),
+                    "frac_bracket": [round(vc["lower"] * scale / simd_cycles, 4), round(vc["upper"] * scale / simd_cycles, 4)],
+                    "lane_utilisation": round(m["lane_utilisation"], 4),
+                    "useful_lane_frac": round(util["valu_issue"] * m["lane_utilisation"], 4),
+                    "utilisation_of_every_unit": {u: round(v, 4) for u, v in util.items()},
+                    "wave_time_waiting_on_memory": round(m["wave_wait_frac"], 3) if m.get("wave_wait_frac") else None,
+                    "traffic": round(pr["hbm_bytes"] * n_l),
+                    "traffic_is": "static: PMC FETCH_SIZE x 2 + WRITE_SIZE of %s (not collected in this run)" % m["source"],
+                    "rays_per_launch": rt.photonsPerLight, "avg_launch_ms": round(avg_ms, 4),
+                    "extend_mray_s": round(rt.photonsPerLight / avg_ms / 1e3, 1),
+                    "clock_assumed_ghz": k["clock_hz"] / 1e9,
+                    "timing_pass": "%d step(s) with launch pipelining off after the timed region; HIP events "
+                                   "around uvrt_extend on its stream" % timing_steps,
+                    "model": "profiles/extend_issue_model.json (%s)" % m.get("note", ""),
+                    "note": "no unit is saturated: the launch is latency-bound (waves spend about half their life in "
+                            "s_waitcnt on record fetches) with VALU issue the busiest unit; packed f32 saves "
+                            "instructions, not issue cycles (DESIGN.md 4)"}
         if census is not None:
+            # secondary: SURVEY.md 8d's HBM-read figure (algorithmic bytes of the REFERENCE's layout, every node
+            # visit priced as a memory read) -- exceeds the peak because the scene is L2/LDS resident
             n = float(census["rays"])
             bytes_per_ray = (32.0 + 8.0 + 32.0 * (1.0 + census["aabb_tests"] / n)
                              + 68.0 * census["tri_tests"] / n + 4.0 * census["hits"] / n)
-            avg_ms = ext_ms / max(ext_launches, 1)
             achieved = bytes_per_ray * rt.photonsPerLight / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "extend_pmc.json")
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            roof = {"bound": "hbm", "kernel": "k_extend6<2,false,true,%s>" % ("true" if args.flavour else "false"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
-                    "rays_per_launch": rt.photonsPerLight, "avg_launch_ms": round(avg_ms, 4),
-                    "extend_mray_s": round(rt.photonsPerLight / avg_ms / 1e3, 1),
-                    "timing_pass": "%d step(s) with launch pipelining off after the timed region; HIP events "
-                                   "around uvrt_extend on its stream" % timing_steps,
-                    "note": "frac > 1 because the scene (5.7 MB) is L2/LDS resident: measured HBM traffic is far "
-                            "below the algorithmic bytes; the kernel is bound by VALU instruction issue (DESIGN.md 4)"}
+            hbm_alg = {"algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "achieved_GBs": round(achieved, 1),
+                       "peak_GBs": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 4),
+                       "note": "SURVEY 8d bookkeeping only: > 1 because node visits are served by L2/LDS; measured HBM "
+                               "traffic is `traffic` above"}
+            if roof is None:
+                roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+            roof["hbm_algorithmic"] = hbm_alg
         out = {
             "metric": "Mray/s (extend+shade) on C046_1.glb 1920x1080x8-bounce", "value": round(value, 2),
             "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

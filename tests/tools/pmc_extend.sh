@@ -1,25 +1,31 @@
 #!/bin/bash
 # Developer probe: rocprofv3 PMC passes over the extend kernel (one variant / sort setting per
-# call).  Usage on the GPU box:  bash tests/tools/pmc_extend.sh <variant> <sort_bits> <outdir>
-# Counters are collected in separate passes (--pmc only, no tracing domains).
+# call).  Usage on the GPU box:  bash tests/tools/pmc_extend.sh <variant> <sort_bits> <outdir> [flavour]
+# Counters are collected in separate passes (--pmc only, no tracing domains); a pass that fails makes
+# the script fail (exit 1) after the remaining passes have run.
 set -u
-V=${1:-0}; S=${2:-0}; OUT=${3:-gpurun_out/pmc_v$V}
+V=${1:-0}; S=${2:-0}; OUT=${3:-gpurun_out/pmc_v$V}; F=${4:-0}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $REPO/$OUT
 cd /tmp && export TMPDIR=/tmp
 PASSES=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU"
  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA"
- "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
- "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TA_TCP_STATE_READ_sum"
+ "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH"
+ "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_BUSY_CU_CYCLES SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INST_LEVEL_VMEM"
+ "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"
+ "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+ "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"
+ "TA_FLAT_READ_WAVEFRONTS_sum TCP_TA_TCP_STATE_READ_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
  "FETCH_SIZE"
  "WRITE_SIZE"
- "GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_CVT SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_INSTS_VALU_ADD_F32"
+ "TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_ATOMIC_sum"
 )
 i=0
+fail=0
 for P in "${PASSES[@]}"; do
-  N=${N:-2073600} VARIANTS=$V SORTS=$S CHECK=0 timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $REPO/$OUT/p$i -- python3 $REPO/tests/tools/quick_extend_bench.py > $REPO/$OUT/p$i.log 2>&1 || echo "pass $i failed"
+  N=${N:-2073600} VARIANTS=$V SORTS=$S FLAVOUR=$F CHECK=0 timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $REPO/$OUT/p$i -- python3 $REPO/tests/tools/quick_extend_bench.py > $REPO/$OUT/p$i.log 2>&1 || { echo "pass $i ($P) FAILED"; fail=1; }
   i=$((i+1))
 done
 python3 - <<PY
@@ -36,3 +42,4 @@ with open("$REPO/$OUT/summary.txt", "w") as o:
         line = "%-40s per-launch avg %16.1f  (launches %d)" % (k, agg[k][0] / agg[k][1], agg[k][1])
         print(line); o.write(line + "\n")
 PY
+exit $fail

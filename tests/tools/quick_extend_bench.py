@@ -18,6 +18,9 @@ sorts = [int(v) for v in os.environ.get("SORTS", "0,-1,12,15,18").split(",")]
 c = pkg.capi.Ctx(0)
 c.set_scene(s.tris, s.nodes, s.triIdx)
 c.resize_rays(n)
+c.set_flavour(int(os.environ.get("FLAVOUR", "0")))
+if os.environ.get("PIPELINE", "1") == "0":
+    c.set_pipeline(False)
 ref = None
 if os.environ.get("CHECK", "1") == "1":
     rays, _ = orc.generate(0, n, lp, route["lightLength"], 0)
