@@ -158,10 +158,9 @@ int uvrt_set_record_perm(uvrt_ctx* ctx, const uint32_t* perm, int32_t n);
  * that cache it across launches must switch the pipelining off.) */
 int uvrt_set_pipeline(uvrt_ctx* ctx, int32_t on);
 
-/* extend kernel variant (developer / A-B knob; every variant is bit-exact): 0 = default (extend v6);
- * 1-99 = the v1-v4 kernels (90 = the v4 default of earlier builds); 200-399 = v5; 400-899 = v6
- * with explicit leaf period / top cache / grid / refill settings; +100 on 0-99, 300-399 and 500-599
- * = IEEE divisions everywhere.  See DESIGN.md section 4. */
+/* extend kernel knobs (developer / A-B; every setting is bit-exact): 0 = default; 400-499 = leaf period /
+ * LDS top cache code + 10 * grid code with refill at 16 idle lanes; 500-599 = the same with IEEE divisions
+ * everywhere; 600-899 = like 400-499 with the refill threshold 8 / 24 / 4 idle lanes.  See DESIGN.md 4. */
 int uvrt_set_variant(uvrt_ctx* ctx, int32_t variant);
 
 /* ---- test / interop hooks ---- */

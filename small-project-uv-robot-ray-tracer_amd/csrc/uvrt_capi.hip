@@ -68,7 +68,7 @@ struct uvrt_ctx {
 
     // scene
     int32_t T = 0;
-    DevBuf pairs, lpairs, recs, perm, ltris, leaf_count, area;
+    DevBuf pairs, recs, perm, ltris, leaf_count, area;
     bool have_perm = false;      // extend v6 record renumbering (uvrt_set_record_perm)
     uint32_t perm_root = 0;
     int32_t npairs = 0;
@@ -84,10 +84,9 @@ struct uvrt_ctx {
     // rays
     int64_t capacity = 0;
     DevBuf rays, keyrank, sorted, order, hits, hist, bin_start, export_buf;
-    DevBuf recip, recip_sorted, ovf_stack;   // f64 reciprocals [3][capacity]; persistent-kernel cursor
+    DevBuf ovf_stack;                          // traversal-stack entries 8..31 of every thread of the persistent grid
     bool recs_valid = false;                   // recs[0, npairs) prepared for the lamp (recs_ox, recs_oz)
     float recs_ox = 0, recs_oz = 0;
-    bool recip_valid = false;                  // recip / recip_sorted hold RN64(1/dir) of the current rays
     bool scene_force_exact = false;            // a node bound too tiny / too large for the reciprocal shortcuts
     int32_t hist_bins = 0;
     int64_t last_n = -1;
@@ -238,18 +237,13 @@ void split_bits(int bits, int& bphi, int& by, int& bo)
     by = bits - bo - bphi;
 }
 
-// Kernel selection (uvrt_set_variant).  0 (default) = extend v6 with the top-of-tree LDS cache, leaf
-// visits every second trip and refill at 8 idle lanes, falling back to the v4 kernel for scenes beyond v6's record numbering;
-// 1-99 = the v1-v4 kernels (launch_extend; 90 = the former default); +100 = the same with IEEE divisions
-// everywhere; 200-299 = v5 (leaf period code + 10 * grid code), 300-399 = v5 with IEEE divisions;
-// 400-499 = v6 (code + 10 * grid code, uvrt_extend6.hip), 500-599 = v6 with IEEE divisions.
-// 600-899 = v6 like 400-499 with the refill threshold 8 / 24 / 4 idle lanes instead of 16.
-bool variant_is_v6(const uvrt_ctx* c)
-{
-    const bool fits = (size_t)c->npairs + (size_t)c->T < ((size_t)1 << 26);   // 32-bit record offsets
-    if (c->variant == 0) return fits;
-    return c->variant >= 400 && c->variant < 900;
-}
+// Kernel knobs (uvrt_set_variant).  0 (default) = the top-of-tree LDS cache, leaf visits every second
+// trip, refill at 8 idle lanes, 8 workgroups per CU; 400-499 = code + 10 * grid code (uvrt_extend6.hip:
+// code bits 0-1 leaf period - 1, bit 2 no LDS cache; grid code 0..4 = 8 / 4 / 6 / 2 / 16 workgroups per CU)
+// with refill at 16 idle lanes; 500-599 = the same with IEEE divisions everywhere; 600-899 = like 400-499
+// with the refill threshold 8 / 24 / 4 idle lanes.  (The v1-v5 kernels of round 1 are gone: see git history
+// and DESIGN.md section 4 for what they measured.)
+bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900); }
 
 int auto_sort_bits(int64_t n)
 {
@@ -323,10 +317,10 @@ void uvrt_destroy(uvrt_ctx* c)
     }
     if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
     if (c->ev_mapfence) (void)hipEventDestroy(c->ev_mapfence);
-    for (DevBuf* b : {&c->pairs, &c->lpairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
+    for (DevBuf* b : {&c->pairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
-                      &c->recip, &c->recip_sorted, &c->ovf_stack, &c->error_flag})
+                      &c->ovf_stack, &c->error_flag})
         b->release();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -421,7 +415,9 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         if (depth[qi] < 7 && top_pairs < 127) top_pairs = (uint32_t)qi + 1;   // level order: a prefix
     }
     if (err) return fail(UVRT_ERR_BVH, "uvrt_set_scene: malformed BVH (code %d)", err);
-    if (pairs.size() >= (size_t)REF_LEAF_BIT) return fail(UVRT_ERR_BVH, "uvrt_set_scene: too many inner nodes");
+    // a child reference is a record index with 32-bit byte offsets: inner-node records + leaf records < 2^26
+    if (pairs.size() + (size_t)T >= ((size_t)1 << 26))
+        return fail(UVRT_ERR_INVALID, "uvrt_set_scene: %zu inner nodes + %d triangles exceed 2^26 records", pairs.size(), T);
 
     if (int rcj = join_all(c)) return rcj;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -429,7 +425,6 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     const bool resized = (T != c->T);
     int rc;
     if ((rc = c->pairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
-    if ((rc = c->lpairs.ensure(std::max<size_t>(pairs.size(), 1) * sizeof(PairRec), false, c->stream))) return rc;
     if ((rc = c->recs.ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
     for (int l = 1; l < c->nlanes; ++l)
         if ((rc = c->xrecs[l].ensure((pairs.size() + (size_t)T + 1) * 64, true, c->stream))) return rc;
@@ -503,8 +498,6 @@ int uvrt_resize_rays(uvrt_ctx* c, int64_t photon_count)
     if ((rc = c->keyrank.ensure(n * 8, false, c->stream))) return rc;
     if ((rc = c->sorted.ensure(n * 16, false, c->stream))) return rc;
     if ((rc = c->order.ensure(n * 4, false, c->stream))) return rc;
-    if ((rc = c->recip.ensure(n * 24, false, c->stream))) return rc;
-    if ((rc = c->recip_sorted.ensure(n * 24, false, c->stream))) return rc;
     if (c->record_hits && (rc = c->hits.ensure(n * 8, false, c->stream))) return rc;
     c->capacity = photon_count;
     c->last_n = -1;
@@ -576,7 +569,7 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (bits > 20) bits = 20;
     // launch lane: alternate between the two streams / buffer sets when nothing stands against it
     {
-        const bool pipe_ok = c->pipeline && c->nlanes > 1 && variant_is_v6(c) && !c->record_hits && bits == 0 &&
+        const bool pipe_ok = c->pipeline && c->nlanes > 1 && !c->record_hits && bits == 0 &&
                              c->xrays[1].p;
         c->prev_lane = c->lane;
         c->cur_pipelined = pipe_ok;
@@ -592,11 +585,6 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     GenParams p;
     memset(&p, 0, sizeof p);
     p.rays = lane_rays(c).as<float4>();
-    // extend v6 derives RN32(1/dir) in the kernel; the f64 reciprocals are only written for the
-    // older kernels (and made up by uvrt_extend if the variant is switched after generate)
-    const bool want_recip = !variant_is_v6(c);
-    p.recip = want_recip ? c->recip.as<double>() : nullptr;
-    p.recip_stride = c->capacity;
     p.lx = lp[0]; p.ly = lp[1]; p.lz = lp[2];
     p.light_length = light_length;
     p.first_gid = first_gid;
@@ -619,7 +607,7 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
         p.hist = c->hist.as<uint32_t>();
         split_bits(bits, p.bits_phi, p.bits_y, p.bits_o);
     }
-    if (!want_recip && c->npairs > 0) {   // v6: its per-launch records ride along in the same launch
+    if (c->npairs > 0) {   // extend's per-launch records ride along in the same launch
         p.prep_pairs = c->pairs.as<PairRec>();
         p.prep_recs = lane_recs(c).as<float4>();
         p.prep_perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
@@ -633,11 +621,9 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (p.keyrank) {
         launch_scan_bins(c->hist.as<uint32_t>(), c->bin_start.as<uint32_t>(), 1 << bits, c->stream);
         launch_scatter(c->rays.as<float4>(), c->keyrank.as<uint2>(), c->bin_start.as<uint32_t>(),
-                       c->sorted.as<float4>(), c->order.as<uint32_t>(),
-                       want_recip ? c->recip_sorted.as<double>() : nullptr, c->capacity, n, c->stream);
+                       c->sorted.as<float4>(), c->order.as<uint32_t>(), n, c->stream);
         HIP_TRY(hipGetLastError());
     }
-    c->recip_valid = want_recip;
     c->seed = seed_next;
     c->last_n = n;
     c->last_first = first_gid;
@@ -668,8 +654,6 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     hipStream_t ls;
     if (int rc = lane_stream(c, &ls)) return rc;
     p.rays = c->last_sorted ? c->sorted.as<float4>() : lane_rays(c).as<float4>();
-    p.recip = c->last_sorted ? c->recip_sorted.as<double>() : c->recip.as<double>();
-    p.recip_stride = c->capacity;
     {
         // conditions of the reciprocal shortcut that are uniform over the launch (slab<>())
         const float ax = std::fabs(c->ox), az = std::fabs(c->oz);
@@ -691,7 +675,6 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.ox = c->ox;
     p.oz = c->oz;
     p.n = n;
-    p.lpairs = c->lpairs.p;
     p.npairs = c->npairs;
     p.recs = lane_recs(c).p;
     p.perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
@@ -714,30 +697,15 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         ++c->ev_used;
         HIP_TRY(hipEventRecord(e0, ls));
     }
-    const bool v6 = variant_is_v6(c);
-    const bool v5 = c->variant >= 200 && c->variant < 400;
-    if ((c->variant >= 100 && c->variant < 200) || (c->variant >= 300 && c->variant < 400) ||
-        (c->variant >= 500 && c->variant < 600))
-        p.force_exact = 1;
+    if (c->variant >= 500 && c->variant < 600) p.force_exact = 1;
     p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
-    if (c->flavour != 0 && !v6 && c->variant != 0 && c->variant != 90)
-        return fail(UVRT_ERR_INVALID, "uvrt_extend: the ocl-amd flavour is implemented by extend v6 and the v4 kernel (variant 90) only");
-    if (c->variant >= 400 && c->variant < 900 && (size_t)c->npairs + (size_t)c->T >= ((size_t)1 << 26))
-        return fail(UVRT_ERR_INVALID, "uvrt_extend: scene too large for extend v6's record numbering");
-    if (!v6 && !c->recip_valid) {
-        // the rays were generated for v6: make up the f64 reciprocals the older kernels read
-        launch_fill_recip(p.rays, const_cast<double*>(p.recip), p.recip_stride, n, ls);
-        c->recip_valid = true;
-    }
-    static const int per_cu5[5] = {8, 4, 6, 2, 16};
-    const int g5 = (c->variant / 10) % 10;
+    static const int per_cu[5] = {8, 4, 6, 2, 16};
+    const int gcode = (c->variant / 10) % 10;
     const int code6 = c->variant == 0 ? 1 : c->variant % 10;   // default: LDS top cache, leaf visits every 2nd trip
     // default grid: 8 workgroups per CU on one stream; with four launch lanes 4 per CU (two launches
     // co-resident fill the GPU, every wave owns twice the rays: a shorter drain per ray)
     const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : 8;
-    if (v6 ? !launch_extend6(p, code6, c->variant == 0 ? per_cu_default : per_cu5[g5 < 5 ? g5 : 0], ls)
-        : v5 ? !launch_extend5(p, c->variant % 10, per_cu5[g5 < 5 ? g5 : 0], ls)
-             : !launch_extend(p, c->variant % 100, ls))
+    if (!launch_extend6(p, code6, c->variant == 0 ? per_cu_default : per_cu[gcode < 5 ? gcode : 0], ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, ls));
@@ -938,6 +906,7 @@ int uvrt_set_flavour(uvrt_ctx* c, int32_t flavour)
 int uvrt_set_variant(uvrt_ctx* c, int32_t variant)
 {
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    if (!variant_ok(variant)) return fail(UVRT_ERR_INVALID, "uvrt_set_variant: %d is not a variant (0, 400-899)", variant);
     c->variant = variant;
     return UVRT_OK;
 }
@@ -980,23 +949,17 @@ int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
     struct HostRay { float d[3], o[3], dist; uint32_t tri; };
     const HostRay* hr = (const HostRay*)rays32;
     std::vector<float> packed((size_t)n * 4);
-    std::vector<double> rec((size_t)n * 3);
     for (int64_t i = 0; i < n; ++i) {
         if (memcmp(&hr[i].o[0], &hr[0].o[0], 4) != 0 || memcmp(&hr[i].o[2], &hr[0].o[2], 4) != 0)
             return fail(UVRT_ERR_INVALID, "uvrt_write_rays: record %lld has a different orig.x/orig.z", (long long)i);
         packed[4 * i + 0] = hr[i].d[0]; packed[4 * i + 1] = hr[i].d[1];
         packed[4 * i + 2] = hr[i].d[2]; packed[4 * i + 3] = hr[i].o[1];
-        for (int k = 0; k < 3; ++k) rec[(size_t)k * n + i] = 1.0 / (double)hr[i].d[k];   // as k_generate does
     }
     if (int rc = join_all(c)) return rc;
     c->lane = 0;
     c->cur_pipelined = false;
     HIP_TRY(hipMemcpyAsync(c->rays.p, packed.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    for (int k = 0; k < 3; ++k)
-        HIP_TRY(hipMemcpyAsync((char*)c->recip.p + (size_t)k * c->capacity * 8, rec.data() + (size_t)k * n,
-                               (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->recip_valid = true;
     c->recs_valid = false;
     c->last_n = n;
     c->last_first = 0;

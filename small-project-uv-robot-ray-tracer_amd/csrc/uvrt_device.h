@@ -66,8 +66,6 @@ __device__ __forceinline__ void prepare_record6(const PairRec* __restrict__ pair
 
 struct GenParams {
     float4* rays;          // [n] gid order: dir.xyz, orig.y
-    double* recip;         // [3][capacity] RN64(1/dir) per component, gid order (nullptr: skip)
-    int64_t recip_stride;  // = ray capacity
     uint2* keyrank;        // [n] (key, rank within key) or nullptr when not sorting
     uint32_t* hist;        // [1 << sort_bits]
     float lx, ly, lz;      // lamp position (generate.cl arg 1)
@@ -90,8 +88,6 @@ struct GenParams {
 struct ExtendParams {
     SceneDev scene;
     const float4* rays;      // [n] in trace order
-    const double* recip;     // [3][recip_stride] RN64(1/dir), trace order
-    int64_t recip_stride;
     uint32_t chunk;          // persistent kernel: trace slots owned by each wavefront
     uint32_t* ovf_stack;     // persistent kernels: [grid threads][MAX_STACK - LDS entries] stack overflow
     uint64_t ovf_capacity;   // entries (uint32) available in ovf_stack; launches that need more are refused
@@ -109,7 +105,6 @@ struct ExtendParams {
     uint32_t* error_flag;    // set to 1 on traversal stack overflow
     float ox, oz;            // launch-uniform origin components
     int64_t n;
-    void* lpairs;            // extend v5: per-launch node-pair records (uvrt_extend5.hip), npairs x 64 B
     int32_t npairs;
     void* recs;              // extend v6: [npairs] per-launch pair records + [T] leaf records, 64 B each
     int32_t refill_min;      // extend v6: idle lanes that trigger a refill (16)
@@ -123,14 +118,9 @@ struct ExtendParams {
 void launch_generate(const GenParams& p, hipStream_t s);
 void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStream_t s);
 void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bin_start,
-                    float4* sorted, uint32_t* order, double* recip_sorted, int64_t recip_stride,
-                    int64_t n, hipStream_t s);
-void launch_fill_recip(const float4* rays, double* recip, int64_t recip_stride, int64_t n, hipStream_t s);
-// returns false (nothing launched) when the variant's grid would not fit the overflow-stack buffer
-bool launch_extend(const ExtendParams& p, int variant, hipStream_t s);
-// extend v5 (uvrt_extend5.hip): leaf_code 0..3 = leaf visits every 1/2/3/4 trips
-bool launch_extend5(const ExtendParams& p, int leaf_code, int grid_per_cu, hipStream_t s);
-// extend v6 (uvrt_extend6.hip), the default: code bits 0-1 = leaf period - 1, bit 2 = no LDS top cache
+                    float4* sorted, uint32_t* order, int64_t n, hipStream_t s);
+// extend (uvrt_extend6.hip): code bits 0-1 = leaf period - 1, bit 2 = no LDS top cache; returns false
+// (nothing launched) when the grid would not fit the overflow-stack buffer
 bool launch_extend6(const ExtendParams& p, int code, int grid_per_cu, hipStream_t s);
 void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, int32_t T, hipStream_t s);
 constexpr uint64_t OVF_MAX_ENTRIES = (uint64_t)256 * 16 * 256 * 24;   // largest grid x deepest overflow

@@ -1,9 +1,10 @@
-// uvrt_extend6.hip -- extend v6 (cl/extend.cl:6-99), the default traversal kernel.
+// uvrt_extend6.hip -- extend (cl/extend.cl:6-99), the traversal kernel ("v6": the sixth generation;
+// DESIGN.md section 4 has what its predecessors measured).
 //
-// Same algorithm as k_extend_persist (uvrt_kernels.hip): persistent wavefronts over statically owned
-// 64-ray batches, in-wave refill, one traversal step per lane and loop trip, the reference's visit
-// order / tests / comparisons.  What differs is the instruction stream of a trip, which is what
-// bounds the kernel (VALU issue, then the L1's one-line-per-clock lookup rate):
+// Persistent wavefronts over statically owned 64-ray batches, in-wave refill, one traversal step per
+// lane and loop trip, the reference's visit order / tests / comparisons.  The instruction stream of a
+// trip is what the design is about (the launch is latency-bound with VALU issue, scalar
+// issue and the L1's lookup rate all at 45-55 % of their calibrated peaks):
 //
 //  * slab distances t = (b - o) / d as PACKED f32, two quotients per instruction:
 //        q0 = a * y;  r = fma(-d, q0, a);  q = fma(r, y, q0)      with y = RN32(1/d)
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     unsigned long long special_mask = 0;   // lanes whose ray needs the EXACT step (wave-uniform value)
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
 
-    // wave w traces the 64-ray batches w, w + W, w + 2W, ... (see k_extend_persist)
+    // wave w traces the 64-ray batches w, w + W, w + 2W, ...: static ownership, no atomics, and batches
+    // dealt round-robin so that ordered rays stay load-balanced
     const uint32_t wave = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t W = gridDim.x * 4u;
     uint32_t cursor = 0;

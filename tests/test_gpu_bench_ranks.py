@@ -40,5 +40,5 @@ def test_two_rank_rehearsal_matches_single_rank():
     assert weak["dose_crc32"] == one["dose_crc32"]
     assert strong["dose_crc32"] == one["dose_crc32"]
     for d in (one, weak, strong):
-        assert d["roofline"] is None or d["roofline"]["unit"] == "GB/s"
+        assert d["roofline"] is None or 0.0 < d["roofline"]["frac"] <= 1.0
         assert d["unit"] == "Mray/s" and d["higher_is_better"] is True

@@ -73,10 +73,10 @@ def test_extend_hits_and_counts_bit_exact(ctx, orc, oscene, oroute, sort_bits):
     ctx.set_record_hits(False)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 6, 7, 8, 9, 12, 27, 90, 100, 200, 201, 202, 203, 204, 206, 212, 300, 306, 400, 401, 402, 403, 404, 405, 411, 421, 500, 505])
+@pytest.mark.parametrize("variant", [0, 400, 401, 402, 403, 404, 405, 406, 407, 411, 421, 431, 441, 500, 505, 601, 702, 801])
 def test_every_extend_variant_is_bit_exact(ctx, orc, oscene, oroute, variant):
-    """All kernel variants (v1 per-ray, persistent with different refill thresholds / grid sizes,
-    LDS-staged cooperative fetch) give the same bits: layout and scheduling never change results."""
+    """All kernel knob settings (leaf period, LDS top cache on / off, 2-16 workgroups per CU, refill
+    thresholds, IEEE divisions everywhere) give the same bits: layout and scheduling never change results."""
     _variant_case(ctx, orc, oscene, oroute, variant, 0)
 
 
