@@ -129,6 +129,50 @@ int uvrt_set_seed_mode(uvrt_ctx* ctx, int32_t mode);
 uint32_t uvrt_seed_next_mode(const float light_pos[3], float light_length, uint32_t seed_prev,
                              int32_t seed_mode);
 
+/* ---- batched tracing: several launches in one go, one count "plane" per launch ----
+ *
+ * A computation is iterations x lamps launches of generate -> extend -> accumulate (raytracer.cpp:66-88).
+ * accumulate.cl:9-13 needs every launch's TOTAL per-triangle count (max), so a job that shards launches by
+ * global-id range over GPUs keeps one int32[T] plane per launch, sums all planes over the ranks ONCE per
+ * batch and then replays accumulate (and the host loop's Shade calls) plane by plane: the f64 maps, the dose
+ * and the colours come out bit-identical to the per-launch sequence.  On one GPU the same calls trace the
+ * launches of a batch in as few kernel launches as their lamps allow (launches of one lamp column share their
+ * per-launch records), which keeps the persistent wavefronts supplied with rays across launch boundaries. */
+typedef struct {
+    float duration;              /* accumulate.cl timeStep of this launch (raytracer.cpp:84) */
+    int32_t shade;               /* != 0: the host loop runs Shade after this launch (myapp.cpp:160) ... */
+    int32_t which_map;           /* ... with these arguments (raytracer.cpp:96-118; UVRT_MAP_SUM / UVRT_MAP_MAX) */
+    int32_t photons_per_light;
+    float scaled_power, min_value;
+    int32_t threshold_view;
+} uvrt_replay_op;
+
+/* generate + extend for `count` launches (<= 64), launch k from lamp lamps[3k..3k+2], all over the global
+ * ids [first_gid, first_gid + n).  The SEED chain advances launch by launch exactly as `count` calls of
+ * uvrt_generate would.  The deposits stay in the batch's planes until uvrt_replay_batch. */
+int uvrt_trace_batch(uvrt_ctx* ctx, const float* lamps, float light_length, int32_t count,
+                     int64_t first_gid, int64_t n);
+/* per launch (logical order): accumulate.cl, then Shade where ops[k].shade is set; ends the batch */
+int uvrt_replay_batch(uvrt_ctx* ctx, const uvrt_replay_op* ops, int32_t count, int32_t tri_count);
+/* sum the deposit replicas of every plane into the int32[count][T] array the reduction works on */
+int uvrt_fold_batch(uvrt_ctx* ctx);
+/* test hook: tempPhotonMap of launch `launch` of the traced batch (folds; after a reduce: the global counts) */
+int uvrt_read_batch_counts(uvrt_ctx* ctx, int32_t launch, int32_t* out, int32_t first, int32_t count);
+
+/* ---- the one collective of a sharded computation (RCCL over xGMI; librccl is opened on first use) ----
+ * One process per GPU: rank 0 calls uvrt_comm_unique_id and hands the 128 bytes to every rank (any
+ * out-of-band channel), every rank calls uvrt_comm_init_rank; then per batch uvrt_trace_batch (its own
+ * global-id range) -> uvrt_reduce_batch (int32 SUM all-reduce of the planes on the context's stream) ->
+ * uvrt_replay_batch.  One process driving several GPUs: uvrt_comm_init_all over one context per device and
+ * uvrt_reduce_batch_group.  uvrt_reduce_batch_group without communicators sums contexts that share ONE
+ * device (rehearsals and tests of the sharded path on a single-GPU box). */
+int uvrt_comm_unique_id(void* id128);
+int uvrt_comm_init_rank(uvrt_ctx* ctx, const void* id128, int32_t rank, int32_t world);
+int uvrt_comm_init_all(uvrt_ctx** ctxs, int32_t n);
+int uvrt_comm_destroy(uvrt_ctx* ctx);
+int uvrt_reduce_batch(uvrt_ctx* ctx);
+int uvrt_reduce_batch_group(uvrt_ctx** ctxs, int32_t n);
+
 /* ---- tuning knobs (results never depend on them) ---- */
 /* bits of the ray-coherence key used to order rays before extend; 0 = trace in gid order
  * (default), -1 = choose from n (about one wavefront of rays per key). */

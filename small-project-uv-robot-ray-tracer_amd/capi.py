@@ -43,6 +43,16 @@ SYMBOLS = [
     ("uvrt_get_seed", C.c_int, [_vp, C.POINTER(_u32)]),
     ("uvrt_set_seed", C.c_int, [_vp, _u32]),
     ("uvrt_seed_next", _u32, [_fp, _f32, _u32]),
+    ("uvrt_trace_batch", C.c_int, [_vp, _fp, _f32, _i32, _i64, _i64]),
+    ("uvrt_replay_batch", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("uvrt_fold_batch", C.c_int, [_vp]),
+    ("uvrt_read_batch_counts", C.c_int, [_vp, _i32, _vp, _i32, _i32]),
+    ("uvrt_comm_unique_id", C.c_int, [_vp]),
+    ("uvrt_comm_init_rank", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("uvrt_comm_init_all", C.c_int, [C.POINTER(_vp), _i32]),
+    ("uvrt_comm_destroy", C.c_int, [_vp]),
+    ("uvrt_reduce_batch", C.c_int, [_vp]),
+    ("uvrt_reduce_batch_group", C.c_int, [C.POINTER(_vp), _i32]),
     ("uvrt_advance_seed", C.c_int, [_vp, _fp, _f32]),
     ("uvrt_set_seed_mode", C.c_int, [_vp, _i32]),
     ("uvrt_seed_next_mode", _u32, [_fp, _f32, _u32, _i32]),
@@ -62,6 +72,10 @@ SYMBOLS = [
     ("uvrt_set_timing", C.c_int, [_vp, _i32]),
     ("uvrt_device_cus", C.c_int, [_vp]),
 ]
+
+# uvrt_replay_op (include/uvrt.h)
+REPLAY_OP_DT = np.dtype([("duration", "<f4"), ("shade", "<i4"), ("which_map", "<i4"), ("photons_per_light", "<i4"),
+                         ("scaled_power", "<f4"), ("min_value", "<f4"), ("threshold_view", "<i4")])
 
 _LIB = None
 
@@ -97,6 +111,31 @@ def _ptr(a):
 def seed_next(light_pos, light_length, seed_prev, seed_mode=0):
     return int(lib().uvrt_seed_next_mode(_f3(light_pos), float(np.float32(light_length)), int(seed_prev),
                                          int(seed_mode)))
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 of a one-process-per-GPU job)."""
+    buf = C.create_string_buffer(128)
+    rc = lib().uvrt_comm_unique_id(buf)
+    if rc != 0:
+        raise UvrtError("uvrt error %d: %s" % (rc, lib().uvrt_last_error().decode()))
+    return buf.raw
+
+
+def _ctx_array(ctxs):
+    return (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+
+
+def comm_init_all(ctxs):
+    rc = lib().uvrt_comm_init_all(_ctx_array(ctxs), len(ctxs))
+    if rc != 0:
+        raise UvrtError("uvrt error %d: %s" % (rc, lib().uvrt_last_error().decode()))
+
+
+def reduce_batch_group(ctxs):
+    rc = lib().uvrt_reduce_batch_group(_ctx_array(ctxs), len(ctxs))
+    if rc != 0:
+        raise UvrtError("uvrt error %d: %s" % (rc, lib().uvrt_last_error().decode()))
 
 
 class Ctx:
@@ -214,6 +253,35 @@ class Ctx:
     @seed.setter
     def seed(self, v):
         self._ck(self._L.uvrt_set_seed(self._h, int(v)))
+
+    def trace_batch(self, lamps, light_length, first_gid, n):
+        lamps = np.ascontiguousarray(lamps, dtype=np.float32).reshape(-1, 3)
+        self._ck(self._L.uvrt_trace_batch(self._h, lamps.ctypes.data_as(_fp), float(np.float32(light_length)),
+                                          lamps.shape[0], int(first_gid), int(n)))
+
+    def replay_batch(self, ops, tri_count=None):
+        """ops: array of REPLAY_OP_DT (or tuples in its field order), one per launch in logical order"""
+        ops = np.ascontiguousarray(np.array(ops, dtype=REPLAY_OP_DT))
+        self._ck(self._L.uvrt_replay_batch(self._h, _ptr(ops), ops.size, self.T if tri_count is None else int(tri_count)))
+
+    def fold_batch(self):
+        self._ck(self._L.uvrt_fold_batch(self._h))
+
+    def read_batch_counts(self, launch, first=0, count=None):
+        count = self.T - first if count is None else count
+        out = np.empty(count, dtype=np.int32)
+        self._ck(self._L.uvrt_read_batch_counts(self._h, int(launch), _ptr(out), first, count))
+        return out
+
+    def comm_init_rank(self, id128, rank, world):
+        assert len(id128) == 128
+        self._ck(self._L.uvrt_comm_init_rank(self._h, C.c_char_p(id128), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ck(self._L.uvrt_comm_destroy(self._h))
+
+    def reduce_batch(self):
+        self._ck(self._L.uvrt_reduce_batch(self._h))
 
     def advance_seed(self, light_pos, light_length):
         self._ck(self._L.uvrt_advance_seed(self._h, _f3(light_pos), float(np.float32(light_length))))

@@ -6,6 +6,9 @@
 #include "../../include/uvrt.h"
 #include "uvrt_device.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl is opened at run time (uvrt_comm_*)
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -119,6 +122,17 @@ struct uvrt_ctx {
     DevBuf xrays[MAXL], xrecs[MAXL], xcounts[MAXL], xovf[MAXL];   // [0] unused: lane 0 has rays, recs, counts, ovf_stack
     bool xrecs_valid[MAXL] = {};
     float xrecs_ox[MAXL] = {}, xrecs_oz[MAXL] = {};
+
+    // Batched tracing (uvrt_trace_batch): the rays of up to MAX_BATCH launches side by side, one count
+    // "plane" (replicas x T ints) per launch, one per-launch record array per distinct lamp.
+    DevBuf b_rays, b_planes, b_folded;
+    std::vector<DevBuf> b_recs;           // [group]
+    int32_t b_count = 0;                  // launches of the batch that has not been replayed (0: none)
+    int64_t b_n = 0, b_npad = 0;
+    int32_t b_phys[MAX_BATCH] = {};       // logical launch -> physical plane (launches are grouped by lamp)
+    bool b_is_folded = false;             // b_folded holds the batch (fold / all-reduce done), the replicas are zero
+    void* comm = nullptr;                 // ncclComm_t of a ray-range-sharded job (uvrt_comm_init_rank)
+    int comm_rank = 0, comm_world = 1;
 
     // generate.cl:6 program-scope SEED
     uint32_t seed = 0;
@@ -317,6 +331,9 @@ void uvrt_destroy(uvrt_ctx* c)
     }
     if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
     if (c->ev_mapfence) (void)hipEventDestroy(c->ev_mapfence);
+    if (c->comm) uvrt_comm_destroy(c);
+    for (DevBuf& b : c->b_recs) b.release();
+    for (DevBuf* b : {&c->b_rays, &c->b_planes, &c->b_folded}) b->release();
     for (DevBuf* b : {&c->pairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
@@ -479,6 +496,12 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->have_perm = false;
     c->have_scene = true;
     c->scene_force_exact = tiny_bound || huge_vertex;
+    // a batch of the previous scene is void; its buffers are sized per scene
+    c->b_count = 0;
+    c->b_is_folded = false;
+    for (DevBuf& b : c->b_recs) b.release();
+    c->b_recs.clear();
+    for (DevBuf* b : {&c->b_planes, &c->b_folded}) b->release();
     return UVRT_OK;
 }
 
@@ -523,6 +546,13 @@ int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
         c->counts_dirty[l] = false;
     }
     c->counts_dirty[0] = false;
+    if (c->b_count > 0) {     // a traced batch that was never replayed: drop its deposits
+        if (c->b_is_folded) HIP_TRY(hipMemsetAsync(c->b_folded.p, 0, c->b_folded.bytes, c->stream));
+        else HIP_TRY(hipMemsetAsync(c->b_planes.p, 0, c->b_planes.bytes, c->stream));
+        c->b_count = 0;
+        c->b_is_folded = false;
+        dirty = true;
+    }
     return dirty ? mark_fence(c) : mark_map_fence(c);
 }
 
@@ -869,6 +899,374 @@ int uvrt_set_seed(uvrt_ctx* c, uint32_t seed)
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
     c->seed = seed;
     return UVRT_OK;
+}
+
+
+// ---------------------------------------------------------------- batched tracing, include/uvrt.h
+
+int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_t count, int64_t first_gid, int64_t n)
+{
+    if (!c || !lamps || !c->have_scene) return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: null argument or no scene");
+    if (count <= 0 || count > MAX_BATCH) return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: count must be in [1,%d]", MAX_BATCH);
+    if (n <= 0 || first_gid < 0 || first_gid + n > (int64_t)INT32_MAX)
+        return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: bad global-id range");
+    if (c->b_count > 0) return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: the previous batch has not been replayed (uvrt_replay_batch)");
+    if (c->record_hits || c->sort_bits != 0)
+        return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: per-ray hit records and ray ordering are per-launch features");
+    if (int rc = set_device(c)) return rc;
+    const int64_t n_pad = (n + 63) / 64 * 64;
+    const int R = c->replicas;
+    if ((uint64_t)count * (uint64_t)n_pad >= ((uint64_t)1 << 30) || (uint64_t)count * (uint64_t)R * (uint64_t)c->T >= ((uint64_t)1 << 32))
+        return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: %d launches x %lld rays exceed one batch (2^30 ray slots, 2^32 counters)", count, (long long)n);
+
+    // group the launches by lamp column (x, z): the per-launch node-pair records depend on it only
+    int group_of[MAX_BATCH], ngroups = 0, gfirst[MAX_BATCH], gsize[MAX_BATCH] = {};
+    float gx[MAX_BATCH], gz[MAX_BATCH];
+    for (int k = 0; k < count; ++k) {
+        int g = 0;
+        for (; g < ngroups; ++g)
+            if (memcmp(&gx[g], &lamps[3 * k], 4) == 0 && memcmp(&gz[g], &lamps[3 * k + 2], 4) == 0) break;
+        if (g == ngroups) { gx[g] = lamps[3 * k]; gz[g] = lamps[3 * k + 2]; ++ngroups; }
+        group_of[k] = g;
+        ++gsize[g];
+    }
+    for (int g = 0, acc = 0; g < ngroups; ++g) { gfirst[g] = acc; acc += gsize[g]; }
+    GenBatchParams gp;
+    memset(&gp, 0, sizeof gp);
+    {
+        int fill[MAX_BATCH] = {};
+        uint32_t seed = c->seed;
+        for (int k = 0; k < count; ++k) {                    // logical order: the SEED chain
+            const int g = group_of[k], ph = gfirst[g] + fill[g]++;
+            c->b_phys[k] = ph;
+            gp.lx[ph] = lamps[3 * k]; gp.ly[ph] = lamps[3 * k + 1]; gp.lz[ph] = lamps[3 * k + 2];
+            gp.seed_prev[ph] = seed;
+            seed = uvrt_seed_next_mode(&lamps[3 * k], light_length, seed, c->seed_mode);
+            gp.seed_next[ph] = seed;
+        }
+        c->seed = seed;
+    }
+    // everything outstanding first (the batch buffers may be re-allocated, the lanes are re-used)
+    if (int rc = join_all(c)) return rc;
+    int rc;
+    const size_t plane_ints = (size_t)R * (size_t)c->T;
+    if (c->b_rays.bytes < (size_t)count * (size_t)n_pad * 16 || c->b_planes.bytes < (size_t)count * plane_ints * 4 ||
+        c->b_folded.bytes < (size_t)count * (size_t)c->T * 4 || (int)c->b_recs.size() < ngroups)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = c->b_rays.ensure((size_t)count * (size_t)n_pad * 16, false, c->stream))) return rc;
+    if ((rc = c->b_planes.ensure((size_t)count * plane_ints * 4, true, c->stream))) return rc;
+    if ((rc = c->b_folded.ensure((size_t)count * (size_t)c->T * 4, true, c->stream))) return rc;
+    while ((int)c->b_recs.size() < ngroups) {
+        DevBuf b;
+        if ((rc = b.ensure(((size_t)c->npairs + (size_t)c->T + 1) * 64, true, c->stream))) return rc;
+        launch_prepare_leaves6(c->ltris.as<LeafTri>(), b.p, c->npairs, c->T, c->stream);
+        c->b_recs.push_back(b);
+    }
+    for (int l = 1; l < c->nlanes; ++l)
+        if ((rc = c->xovf[l].ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream))) return rc;
+
+    gp.rays = c->b_rays.as<float4>();
+    gp.n_pad = n_pad;
+    gp.first_gid = first_gid;
+    gp.n = n;
+    gp.light_length = light_length;
+    gp.seed_mode = c->seed_mode;
+    gp.count = count;
+    launch_generate_batch(gp, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (int rcf = mark_fence(c)) return rcf;         // the lanes' next work waits for the generate
+    const int lane_before = c->lane;
+    for (int g = 0; g < ngroups; ++g) {
+        c->lane = (c->pipeline && c->nlanes > 1) ? g % c->nlanes : 0;
+        hipStream_t ls;
+        if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }
+        launch_prepare_launch6(c->pairs.as<PairRec>(), c->b_recs[g].p, gx[g], gz[g], c->npairs,
+                               c->have_perm ? c->perm.as<uint32_t>() : nullptr, ls);
+        ExtendParams p;
+        memset(&p, 0, sizeof p);
+        p.scene.pairs = c->pairs.as<PairRec>();
+        p.scene.ltris = c->ltris.as<LeafTri>();
+        p.scene.leaf_count = c->leaf_count.as<uint32_t>();
+        p.scene.root_ref = c->root_ref;
+        p.scene.tri_count = c->T;
+        p.rays = c->b_rays.as<float4>() + (size_t)gfirst[g] * (size_t)n_pad;
+        {
+            const float ax = std::fabs(gx[g]), az = std::fabs(gz[g]);
+            const float tiny = 7.888609e-31f;   // 2^-100
+            p.force_exact = (c->scene_force_exact || (ax != 0.0f && ax < tiny) || (az != 0.0f && az < tiny) ||
+                             !(ax <= 1e9f) || !(az <= 1e9f) || (c->variant >= 500 && c->variant < 600)) ? 1 : 0;
+        }
+        p.ovf_stack = lane_ovf(c).as<uint32_t>();
+        p.ovf_capacity = lane_ovf(c).bytes / sizeof(uint32_t);
+        p.num_cus = c->num_cus;
+        p.flavour = c->flavour;
+        p.top_pairs = c->top_pairs;
+        p.counts = c->b_planes.as<int32_t>() + (size_t)gfirst[g] * plane_ints;
+        p.count_replicas = R;
+        p.count_stride = c->T;
+        p.error_flag = c->error_flag.as<uint32_t>();
+        p.ox = gx[g];
+        p.oz = gz[g];
+        p.n = (int64_t)gsize[g] * n_pad;
+        p.npairs = c->npairs;
+        p.recs = c->b_recs[g].p;
+        p.perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
+        p.perm_root = c->perm_root;
+        p.recs_prepared = 1;
+        p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
+        p.plane_batches = (uint32_t)(n_pad / 64);
+        p.plane_n = (uint32_t)n;
+        p.plane_stride = (uint32_t)plane_ints;
+        static const int per_cu[5] = {8, 4, 6, 2, 16};
+        const int gcode = (c->variant / 10) % 10;
+        if (!launch_extend6(p, c->variant == 0 ? 1 : c->variant % 10, c->variant == 0 ? 8 : per_cu[gcode < 5 ? gcode : 0], ls)) {
+            c->lane = lane_before;
+            return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: variant %d needs a larger overflow-stack buffer", c->variant);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    c->lane = 0;
+    c->cur_pipelined = false;
+    c->last_n = -1;                      // the per-launch generate/extend pairing starts afresh
+    c->b_count = count;
+    c->b_n = n;
+    c->b_npad = n_pad;
+    c->b_is_folded = false;
+    return UVRT_OK;
+}
+
+int uvrt_fold_batch(uvrt_ctx* c)
+{
+    if (!c || c->b_count <= 0) return fail(UVRT_ERR_INVALID, "uvrt_fold_batch: no traced batch");
+    if (c->b_is_folded) return UVRT_OK;
+    if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
+    launch_fold_planes(c->b_planes.as<int32_t>(), c->b_folded.as<int32_t>(), c->b_count, c->replicas, c->T, c->stream);
+    HIP_TRY(hipGetLastError());
+    c->b_is_folded = true;
+    return mark_fence(c);
+}
+
+int uvrt_replay_batch(uvrt_ctx* c, const uvrt_replay_op* ops, int32_t count, int32_t tri_count)
+{
+    if (!c || !ops || c->b_count <= 0) return fail(UVRT_ERR_INVALID, "uvrt_replay_batch: no traced batch");
+    if (count != c->b_count) return fail(UVRT_ERR_INVALID, "uvrt_replay_batch: %d operations for a batch of %d launches", count, c->b_count);
+    if (tri_count < 0 || tri_count > c->T) return fail(UVRT_ERR_INVALID, "uvrt_replay_batch: bad tri_count");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
+    ReplayParams p;
+    memset(&p, 0, sizeof p);
+    p.photon_map = c->photon_map.as<double>();
+    p.max_map = c->max_map.as<double>();
+    p.planes = c->b_planes.as<int32_t>();
+    p.folded = c->b_folded.as<int32_t>();
+    p.dosage = c->dosage.as<float>();
+    p.color = c->color.as<float>();
+    p.area = c->area.as<float>();
+    p.plane_stride = (int64_t)c->replicas * c->T;
+    p.replicas = c->replicas;
+    p.T = tri_count;
+    p.count = count;
+    p.is_folded = c->b_is_folded ? 1 : 0;
+    for (int k = 0; k < count; ++k) {
+        if (ops[k].which_map != UVRT_MAP_SUM && ops[k].which_map != UVRT_MAP_MAX)
+            return fail(UVRT_ERR_INVALID, "uvrt_replay_batch: which_map must be 0 or 1");
+        p.ops[k].plane = c->b_phys[k];
+        p.ops[k].duration = ops[k].duration;
+        p.ops[k].shade = ops[k].shade;
+        p.ops[k].which_map = ops[k].which_map;
+        p.ops[k].photons_per_light = ops[k].photons_per_light;
+        p.ops[k].scaled_power = ops[k].scaled_power;
+        p.ops[k].min_value = ops[k].min_value;
+        p.ops[k].threshold_view = ops[k].threshold_view;
+    }
+    launch_replay_batch(p, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (tri_count < c->T) {     // a partial replay (calibration's 2-triangle scene never does this): clear the rest
+        if (c->b_is_folded) HIP_TRY(hipMemsetAsync(c->b_folded.p, 0, c->b_folded.bytes, c->stream));
+        else HIP_TRY(hipMemsetAsync(c->b_planes.p, 0, c->b_planes.bytes, c->stream));
+    }
+    c->b_count = 0;
+    c->b_is_folded = false;
+    return mark_fence(c);
+}
+
+int uvrt_read_batch_counts(uvrt_ctx* c, int32_t launch, int32_t* out, int32_t first, int32_t count)
+{
+    if (!c || c->b_count <= 0 || launch < 0 || launch >= c->b_count)
+        return fail(UVRT_ERR_INVALID, "uvrt_read_batch_counts: no such launch in the traced batch");
+    if (int rc = uvrt_fold_batch(c)) return rc;
+    if (!out || first < 0 || count < 0 || first + count > c->T) return fail(UVRT_ERR_INVALID, "uvrt_read_batch_counts: bad range");
+    if (count == 0) return UVRT_OK;
+    HIP_TRY(hipMemcpyAsync(out, c->b_folded.as<int32_t>() + (size_t)c->b_phys[launch] * c->T + first, (size_t)count * 4,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return UVRT_OK;
+}
+
+
+// ---------------------------------------------------------------- RCCL (one all-reduce per computation)
+//
+// librccl is opened lazily with dlopen: a process that never shards (the common case) does not load it,
+// and one that already holds an RCCL (torch.distributed) gets that same library by its soname.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return UVRT_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return fail(UVRT_ERR_HIP, "uvrt_comm: cannot open librccl (%s)", dlerror());
+#define UVRT_SYM(field, sym)                                                                   \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(h, #sym);                                      \
+    if (!g_rccl.field) return fail(UVRT_ERR_HIP, "uvrt_comm: librccl lacks " #sym)
+    UVRT_SYM(GetUniqueId, ncclGetUniqueId);
+    UVRT_SYM(CommInitRank, ncclCommInitRank);
+    UVRT_SYM(CommInitAll, ncclCommInitAll);
+    UVRT_SYM(CommDestroy, ncclCommDestroy);
+    UVRT_SYM(AllReduce, ncclAllReduce);
+    UVRT_SYM(GroupStart, ncclGroupStart);
+    UVRT_SYM(GroupEnd, ncclGroupEnd);
+    UVRT_SYM(GetErrorString, ncclGetErrorString);
+#undef UVRT_SYM
+    g_rccl.lib = h;
+    return UVRT_OK;
+}
+#define RCCL_TRY(expr)                                                                         \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return fail(UVRT_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));        \
+    } while (0)
+}  // namespace
+
+int uvrt_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(UVRT_ERR_INVALID, "uvrt_comm_unique_id: null pointer");
+    if (int rc = rccl_load()) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "the ABI hands the id over as 128 bytes");
+    RCCL_TRY(g_rccl.GetUniqueId((ncclUniqueId*)id128));
+    return UVRT_OK;
+}
+
+int uvrt_comm_init_rank(uvrt_ctx* c, const void* id128, int32_t rank, int32_t world)
+{
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_rank: bad argument");
+    if (c->comm) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_rank: the context already has a communicator");
+    if (int rc = rccl_load()) return rc;
+    if (int rc = set_device(c)) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return UVRT_OK;
+}
+
+int uvrt_comm_init_all(uvrt_ctx** ctxs, int32_t n)
+{
+    if (!ctxs || n < 1 || n > 64) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_all: bad argument");
+    int devs[64];
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->comm) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_all: null context or communicator present");
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i])
+                return fail(UVRT_ERR_INVALID, "uvrt_comm_init_all: contexts %d and %d share device %d (RCCL wants one rank "
+                            "per device; uvrt_reduce_batch_group sums contexts of one device without it)", j, i, devs[i]);
+    }
+    if (int rc = rccl_load()) return rc;
+    ncclComm_t comms[64];
+    RCCL_TRY(g_rccl.CommInitAll(comms, n, devs));
+    for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_rank = i; ctxs[i]->comm_world = n; }
+    return UVRT_OK;
+}
+
+int uvrt_comm_destroy(uvrt_ctx* c)
+{
+    if (!c || !c->comm) return UVRT_OK;
+    if (g_rccl.lib) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+    }
+    c->comm = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+    return UVRT_OK;
+}
+
+int uvrt_reduce_batch(uvrt_ctx* c)
+{
+    if (!c || c->b_count <= 0) return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch: no traced batch");
+    if (!c->comm) return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch: no communicator (uvrt_comm_init_rank / uvrt_comm_init_all)");
+    if (int rc = uvrt_fold_batch(c)) return rc;
+    if (int rc = set_device(c)) return rc;
+    RCCL_TRY(g_rccl.AllReduce(c->b_folded.p, c->b_folded.p, (size_t)c->b_count * (size_t)c->T, ncclInt32, ncclSum,
+                              (ncclComm_t)c->comm, c->stream));
+    return mark_fence(c);
+}
+
+int uvrt_reduce_batch_group(uvrt_ctx** ctxs, int32_t n)
+{
+    if (!ctxs || n < 1) return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->b_count <= 0 || ctxs[i]->b_count != ctxs[0]->b_count || ctxs[i]->T != ctxs[0]->T)
+            return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: context %d holds no batch of the same shape", i);
+        if (int rc = uvrt_fold_batch(ctxs[i])) return rc;
+    }
+    if (n == 1) return UVRT_OK;
+    const size_t count = (size_t)ctxs[0]->b_count * (size_t)ctxs[0]->T;
+    if (ctxs[0]->comm) {          // one process, one device per context: a grouped RCCL all-reduce
+        if (int rc = rccl_load()) return rc;
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int i = 0; i < n; ++i) {
+            if (!ctxs[i]->comm) { (void)g_rccl.GroupEnd(); return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: context %d has no communicator", i); }
+            HIP_TRY(hipSetDevice(ctxs[i]->device));
+            RCCL_TRY(g_rccl.AllReduce(ctxs[i]->b_folded.p, ctxs[i]->b_folded.p, count, ncclInt32, ncclSum,
+                                      (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        for (int i = 0; i < n; ++i) if (int rc = mark_fence(ctxs[i])) return rc;
+        return UVRT_OK;
+    }
+    // contexts of ONE device (rehearsals, tests): sum on context 0's stream, hand the result to the others
+    for (int i = 1; i < n; ++i)
+        if (ctxs[i]->device != ctxs[0]->device)
+            return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: contexts on different devices need uvrt_comm_init_all first");
+    uvrt_ctx* c0 = ctxs[0];
+    if (int rc = set_device(c0)) return rc;
+    for (int i = 1; i < n; ++i) {
+        HIP_TRY(hipEventRecord(ctxs[i]->ev_tail[0], ctxs[i]->stream));
+        HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev_tail[0], 0));
+        launch_add_counts(c0->b_folded.as<int32_t>(), ctxs[i]->b_folded.as<int32_t>(), (int64_t)count, c0->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    for (int i = 1; i < n; ++i)
+        HIP_TRY(hipMemcpyAsync(ctxs[i]->b_folded.p, c0->b_folded.p, count * 4, hipMemcpyDeviceToDevice, c0->stream));
+    HIP_TRY(hipEventRecord(c0->ev_tail[0], c0->stream));
+    for (int i = 1; i < n; ++i) {
+        HIP_TRY(hipStreamWaitEvent(ctxs[i]->stream, c0->ev_tail[0], 0));
+        if (int rc = mark_fence(ctxs[i])) return rc;
+    }
+    return mark_fence(c0);
 }
 
 int uvrt_advance_seed(uvrt_ctx* c, const float lp[3], float light_length)

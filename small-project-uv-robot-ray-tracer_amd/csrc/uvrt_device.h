@@ -64,6 +64,97 @@ __device__ __forceinline__ void prepare_record6(const PairRec* __restrict__ pair
     recs[i * 4 + 3] = make_float4(__uint_as_float(r0), __uint_as_float(r1), 0.f, 0.f);
 }
 
+// ------------------------------------------------------------------ RNG, cl/tools.cl:2-4
+
+__device__ __forceinline__ uint32_t wang_hash(uint32_t s)
+{
+    s = (s ^ 61u) ^ (s >> 16);
+    s *= 9u;
+    s = s ^ (s >> 4);
+    s *= 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    return s;
+}
+
+__device__ __forceinline__ float random_float(uint32_t& s)
+{
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return (float)s * 2.3283064365387e-10f;
+}
+
+// cl/generate.cl:11-37 for work-item `gid`: returns {dir.xyz, orig.y} (orig.x / orig.z are the lamp's).
+// r0 = the first random float (position on the rod), (x, y) = the accepted disc sample: for the optional
+// coherence key of k_generate.  seed_mode: include/uvrt.h uvrt_set_seed_mode.
+__device__ __forceinline__ float4 generate_ray(float lx, float ly, float lz, float light_length, int64_t gid,
+                                               uint32_t seed_prev, uint32_t seed_next, int32_t seed_mode,
+                                               float& r0, double& x, double& y)
+{
+    const int threadID = (int)gid;                       // generate.cl:11 (int threadID)
+    const uint32_t SEED = (gid == 0 || seed_mode == 1) ? seed_prev : seed_next;
+
+    // generate.cl:13 -- f32 adds in source order, then float -> uint through int64
+    float acc = (float)(threadID * 17 + 1);
+    acc = acc + lx * 13.0f;
+    acc = acc + ly * 7.0f;
+    acc = acc + lz * 11.0f;
+    acc = acc + (float)(SEED >> 15);
+    uint32_t seed = wang_hash((seed_mode == 1 && acc < 0.0f) ? 0u : (uint32_t)(int64_t)acc);
+
+    r0 = random_float(seed);
+    const float origy = ly + r0 * light_length;          // :16
+    const float diry = random_float(seed) * 2.0f - 1.0f; // :22
+    const double dirxzlength = sqrt(1.0 - (double)diry * (double)diry);   // :23
+
+    x = (double)(random_float(seed) * 2.0f - 1.0f);                       // :25
+    y = (double)(random_float(seed) * 2.0f - 1.0f);
+    while (x * x + y * y > 1.0) {                                         // :26-28
+        x = (double)(random_float(seed) * 2.0f - 1.0f);
+        y = (double)(random_float(seed) * 2.0f - 1.0f);
+    }
+    const double s = dirxzlength / sqrt(x * x + y * y);                   // :29
+    return make_float4((float)(x * s), diry, (float)(y * s), origy);      // :31-37
+}
+
+// ---- batched tracing (include/uvrt.h uvrt_trace_batch): several launches' rays side by side ----
+constexpr int MAX_BATCH = 64;          // launches per uvrt_trace_batch / uvrt_replay_batch call
+
+struct GenBatchParams {
+    float4* rays;                      // [count][n_pad]: physical plane p at rays + p * n_pad
+    int64_t n_pad;                     // rays per plane in the buffer (n rounded up to 64)
+    int64_t first_gid, n;              // global ids [first_gid, first_gid + n) of EVERY launch
+    float light_length;
+    int32_t seed_mode;
+    int32_t count;
+    float lx[MAX_BATCH], ly[MAX_BATCH], lz[MAX_BATCH];       // lamp of physical plane p
+    uint32_t seed_prev[MAX_BATCH], seed_next[MAX_BATCH];     // its place in the SEED chain
+};
+
+// one entry of uvrt_replay_batch, in LOGICAL launch order
+struct ReplayOp {
+    int32_t plane;                     // physical plane of this launch
+    float duration;                    // accumulate.cl timeStep
+    int32_t shade;                     // run computeDosage + dosageToColor after this launch
+    int32_t which_map;                 // 0 photonMap, 1 maxPhotonMap
+    int32_t photons_per_light;
+    float scaled_power, min_value;
+    int32_t threshold_view;
+};
+
+struct ReplayParams {
+    double* photon_map;
+    double* max_map;
+    int32_t* planes;                   // [plane][replicas][T] deposit replicas (folded == 0)
+    int32_t* folded;                   // [plane][T] sums over the replicas (folded == 1)
+    float* dosage;
+    float* color;
+    const float* area;
+    int64_t plane_stride;              // ints between planes of `planes` (= replicas * T)
+    int32_t replicas, T, count, is_folded;
+    ReplayOp ops[MAX_BATCH];
+};
+
 struct GenParams {
     float4* rays;          // [n] gid order: dir.xyz, orig.y
     uint2* keyrank;        // [n] (key, rank within key) or nullptr when not sorting
@@ -112,10 +203,23 @@ struct ExtendParams {
     uint32_t perm_root;      // perm[0]
     int32_t recs_prepared;   // extend v6: recs[0, npairs) already hold this launch's records (k_generate)
     uint32_t root_ref6;      // root reference in v6's record numbering (set by launch_extend6)
+    // batched tracing: `rays` holds nplanes planes of plane_batches * 64 slots each, of which the first
+    // plane_n are rays; the deposits of plane k go to counts + k * plane_stride (+ replica * count_stride).
+    // plane_batches == 0: one launch, n rays, no planes.
+    uint32_t plane_batches;
+    uint32_t plane_n;
+    uint32_t plane_stride;
 };
 
 // launch wrappers (uvrt_kernels.hip)
 void launch_generate(const GenParams& p, hipStream_t s);
+void launch_generate_batch(const GenBatchParams& p, hipStream_t s);
+// folded[p][i] = sum over the replicas of plane p, replicas zeroed (the all-reduce payload)
+void launch_fold_planes(int32_t* planes, int32_t* folded, int32_t nplanes, int32_t replicas, int32_t T, hipStream_t s);
+void launch_replay_batch(const ReplayParams& p, hipStream_t s);
+void launch_add_counts(int32_t* dst, const int32_t* src, int64_t n, hipStream_t s);     // dst[i] += src[i]
+void launch_prepare_launch6(const PairRec* pairs, void* recs, float ox, float oz, int32_t npairs, const uint32_t* perm,
+                            hipStream_t s);
 void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStream_t s);
 void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bin_start,
                     float4* sorted, uint32_t* order, int64_t n, hipStream_t s);

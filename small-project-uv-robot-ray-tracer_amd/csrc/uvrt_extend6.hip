@@ -314,6 +314,8 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     bool live = false;             // RECORD: holds a ray whose (dist, triID) has not been written yet
     unsigned long long special_mask = 0;   // lanes whose ray needs the EXACT step (wave-uniform value)
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
+    uint32_t plane_off = 0;        // ints from my_counts to the plane of the ray this lane holds
+    const float plane_inv = 1.0f / (float)p.plane_batches;
 
     // wave w traces the 64-ray batches w, w + W, w + 2W, ...: static ownership, no atomics, and batches
     // dealt round-robin so that ordered rays stay load-balanced
@@ -335,14 +337,22 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                     const uint32_t li = p.order ? p.order[slot] : slot;
                     p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
                 }
-                if (L.po.y != 1e30f) atomicAdd(&my_counts[L.triID], 1);
+                if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);
                 live = false;
                 L.po.y = 1e30f;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                       __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
                 const uint32_t v = cursor + rank;
-                const uint32_t my = ((v >> 6) * W + wave) * 64u + (v & 63u);
-                if (v < chunk_end && my < n32) {
+                const uint32_t gb = (v >> 6) * W + wave;                 // global 64-slot batch
+                const uint32_t my = gb * 64u + (v & 63u);
+                // plane (= launch of a batched trace) of the batch: gb / plane_batches, exact after one
+                // correction step (gb < 2^24 is exact in f32, the rounded reciprocal is off by < 1)
+                uint32_t pl = (uint32_t)((float)gb * plane_inv);
+                int32_t within = (int32_t)(gb - pl * p.plane_batches);
+                if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
+                else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
+                if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
+                    set_in_place(plane_off, pl * p.plane_stride);
                     const float4 rec = p.rays[my];
                     // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
                     // and never use y)
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
         const uint32_t li = p.order ? p.order[slot] : slot;
         p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
     }
-    if (L.po.y != 1e30f) atomicAdd(&my_counts[L.triID], 1);           // extend.cl:94-98
+    if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);   // extend.cl:94-98
 }
 
 // Per-launch node-pair records recs[0, P): the lamp's x and z subtracted from the x / z bounds (the
@@ -412,6 +422,14 @@ __global__ __launch_bounds__(256) void k_prepare_leaves6(const LeafTri* __restri
     out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+void launch_prepare_launch6(const PairRec* pairs, void* recs, float ox, float oz, int32_t npairs, const uint32_t* perm,
+                            hipStream_t s)
+{
+    if (npairs <= 0) return;
+    hipLaunchKernelGGL(k_prepare_launch6, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, pairs, (float4*)recs,
+                       ox, oz, npairs, perm);
+}
+
 void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, int32_t T, hipStream_t s)
 {
     if (T <= 0) return;
@@ -426,6 +444,11 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
     ExtendParams p = p0;
     const unsigned cus = p.num_cus > 0 ? (unsigned)p.num_cus : 256u;
     unsigned grid = cus * (unsigned)grid_per_cu;
+    if (p.plane_batches == 0) {      // one launch: a single plane that holds all n rays
+        p.plane_batches = (uint32_t)((p.n + 63) / 64);
+        p.plane_n = (uint32_t)p.n;
+        p.plane_stride = 0;
+    }
     const unsigned need = (unsigned)((p.n + 255) / 256);
     if (need < grid) grid = need;
     const uint64_t waves = (uint64_t)grid * 4;

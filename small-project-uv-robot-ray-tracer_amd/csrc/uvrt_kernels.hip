@@ -15,26 +15,6 @@
 
 namespace uvrt {
 
-// ------------------------------------------------------------------ RNG, cl/tools.cl:2-4
-
-__device__ __forceinline__ uint32_t wang_hash(uint32_t s)
-{
-    s = (s ^ 61u) ^ (s >> 16);
-    s *= 9u;
-    s = s ^ (s >> 4);
-    s *= 0x27d4eb2du;
-    s = s ^ (s >> 15);
-    return s;
-}
-
-__device__ __forceinline__ float random_float(uint32_t& s)
-{
-    s ^= s << 13;
-    s ^= s >> 17;
-    s ^= s << 5;
-    return (float)s * 2.3283064365387e-10f;
-}
-
 // --------------------------------------------------------------- generate, cl/generate.cl
 
 // Spread the quantised (azimuth, elevation, height) of a photon over one key so that rays
@@ -62,32 +42,11 @@ __global__ __launch_bounds__(256) void k_generate(GenParams p)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const int64_t gid = p.first_gid + i;
-    const int threadID = (int)gid;                       // generate.cl:11 (int threadID)
-    const uint32_t SEED = (gid == 0 || p.seed_mode == 1) ? p.seed_prev : p.seed_next;
-
-    // generate.cl:13 -- f32 adds in source order, then float -> uint through int64
-    float acc = (float)(threadID * 17 + 1);
-    acc = acc + p.lx * 13.0f;
-    acc = acc + p.ly * 7.0f;
-    acc = acc + p.lz * 11.0f;
-    acc = acc + (float)(SEED >> 15);
-    uint32_t seed = wang_hash((p.seed_mode == 1 && acc < 0.0f) ? 0u : (uint32_t)(int64_t)acc);
-
-    const float r0 = random_float(seed);
-    const float origy = p.ly + r0 * p.light_length;      // :16
-    const float diry = random_float(seed) * 2.0f - 1.0f; // :22
-    const double dirxzlength = sqrt(1.0 - (double)diry * (double)diry);   // :23
-
-    double x = (double)(random_float(seed) * 2.0f - 1.0f);                // :25
-    double y = (double)(random_float(seed) * 2.0f - 1.0f);
-    while (x * x + y * y > 1.0) {                                         // :26-28
-        x = (double)(random_float(seed) * 2.0f - 1.0f);
-        y = (double)(random_float(seed) * 2.0f - 1.0f);
-    }
-    const double s = dirxzlength / sqrt(x * x + y * y);                   // :29
-    const float dirx = (float)(x * s);
-    const float dirz = (float)(y * s);
-    p.rays[i] = make_float4(dirx, diry, dirz, origy);                     // :31-37
+    float r0;
+    double x, y;
+    const float4 ray = generate_ray(p.lx, p.ly, p.lz, p.light_length, gid, p.seed_prev, p.seed_next, p.seed_mode, r0, x, y);
+    const float diry = ray.y;
+    p.rays[i] = ray;                                                      // :31-37
 
     if (p.keyrank) {
         // azimuth as a diamond angle in [0,4): monotone in the true angle, one division
@@ -103,6 +62,19 @@ __global__ __launch_bounds__(256) void k_generate(GenParams p)
         const uint32_t rank = atomicAdd(&p.hist[key], 1u);
         p.keyrank[i] = make_uint2(key, rank);
     }
+}
+
+// The rays of several launches side by side (uvrt_trace_batch): blockIdx.y = physical plane, every plane
+// generates the same global-id range under its own lamp and place in the SEED chain.
+__global__ __launch_bounds__(256) void k_generate_batch(GenBatchParams p)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const int k = blockIdx.y;
+    float r0;
+    double x, y;
+    p.rays[(int64_t)k * p.n_pad + i] = generate_ray(p.lx[k], p.ly[k], p.lz[k], p.light_length, p.first_gid + i,
+                                                    p.seed_prev[k], p.seed_next[k], p.seed_mode, r0, x, y);
 }
 
 // Exclusive prefix sum over the key histogram (one 1024-thread workgroup; nbins <= 2^20), and
@@ -190,6 +162,109 @@ __global__ __launch_bounds__(256) void k_fold_counts(int32_t* __restrict__ count
     counts[i] = total;
 }
 
+// shade.cl:4-21
+__device__ __forceinline__ void heatmap(float intensity, float& r, float& g, float& b)
+{
+    const float minDosageColor = 0.5f;
+    const float upperHalfColor = 0.75f;   // 0.5f + (1.0 - 0.5f) / 2, exact
+    const float lowerHalfColor = 0.25f;   // 0.5f / 2.0f, exact
+    if (intensity > minDosageColor) {
+        if (intensity > upperHalfColor) {
+            r = 1.0f; g = (1.0f - intensity) / (1.0f - upperHalfColor); b = 0.0f;
+        } else {
+            r = (intensity - minDosageColor) / (upperHalfColor - minDosageColor);
+            g = 1.0f; b = 0.0f;
+        }
+    } else {
+        if (intensity > lowerHalfColor) {
+            r = 0.0f; g = 1.0f;
+            b = (minDosageColor - intensity) / (minDosageColor - lowerHalfColor);
+        } else {
+            r = 0.0f; g = intensity / lowerHalfColor; b = 1.0f;
+        }
+    }
+}
+
+// Batched tracing: per plane the (exact, integer) sum of its deposit replicas -- the int32 payload of the one
+// all-reduce of a ray-range-sharded computation -- and the replicas zeroed for the next batch.
+__global__ __launch_bounds__(256) void k_fold_planes(int32_t* __restrict__ planes, int32_t* __restrict__ folded,
+                                                     int32_t replicas, int32_t T)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int i = g >> 2, part = g & 3;
+    int32_t* pl = planes + (int64_t)blockIdx.y * replicas * T;
+    int32_t total = 0;
+    if (i < T) {
+        for (int r = part; r < replicas; r += 4) {
+            total += pl[(int64_t)r * T + i];
+            pl[(int64_t)r * T + i] = 0;
+        }
+    }
+    total += __builtin_amdgcn_mov_dpp(total, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    total += __builtin_amdgcn_mov_dpp(total, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    if (i < T && part == 0) folded[(int64_t)blockIdx.y * T + i] = total;
+}
+
+// Replay of a batch in LOGICAL launch order, one quad of lanes per triangle: for every launch the
+// reference's accumulate (cl/accumulate.cl:4-14: same f64 additions in the same order, max over the
+// per-launch totals) and, where the host loop has a Shade behind it (raytracer.cpp:93-120), computeDosage +
+// dosageToColor with that Shade's arguments.  The planes are left zeroed.
+__global__ __launch_bounds__(256) void k_replay_batch(ReplayParams p)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int i = g >> 2, part = g & 3;
+    const bool in = i < p.T;
+    double pm = 0, mm = 0;
+    if (in && part == 0) { pm = p.photon_map[i]; mm = p.max_map[i]; }
+    for (int k = 0; k < p.count; ++k) {
+        const ReplayOp op = p.ops[k];
+        int32_t total = 0;
+        if (p.is_folded) {
+            if (in && part == 0) {
+                int32_t* f = p.folded + (int64_t)op.plane * p.T + i;
+                total = *f;
+                *f = 0;
+            }
+        } else {
+            if (in) {
+                int32_t* pl = p.planes + (int64_t)op.plane * p.plane_stride;
+                for (int r = part; r < p.replicas; r += 4) {
+                    total += pl[(int64_t)r * p.T + i];
+                    pl[(int64_t)r * p.T + i] = 0;
+                }
+            }
+            total += __builtin_amdgcn_mov_dpp(total, 0xb1, 0xf, 0xf, true);
+            total += __builtin_amdgcn_mov_dpp(total, 0x4e, 0xf, 0xf, true);
+        }
+        if (!in || part != 0) continue;
+        const double c = (double)total;                                   // accumulate.cl:9-13
+        pm = pm + c * (double)op.duration;
+        mm = mm < c ? c : mm;
+        if (op.shade) {                                                   // shade.cl:23-41, 43-71
+            const double num = (double)op.scaled_power * (op.which_map ? mm : pm);
+            const float den = p.area[i] * (float)op.photons_per_light;
+            const float dose = (float)(num / (double)den);
+            p.dosage[i] = dose;
+            const float maxValue = op.min_value * 2;
+            const float norm = dose / maxValue;
+            float r, gg, b;
+            if (op.threshold_view && norm < 0.5f) { r = 0.0f; gg = 0.0f; b = norm * 2.0f; }
+            else heatmap(norm, r, gg, b);
+            float* col = p.color + (int64_t)i * 9;
+            col[0] = r; col[1] = gg; col[2] = b;
+            col[3] = r; col[4] = gg; col[5] = b;
+            col[6] = r; col[7] = gg; col[8] = b;
+        }
+    }
+    if (in && part == 0) { p.photon_map[i] = pm; p.max_map[i] = mm; }
+}
+
+__global__ __launch_bounds__(256) void k_add_counts(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 // reset.cl:4-26
 __global__ __launch_bounds__(256) void k_reset(double* __restrict__ photon_map,
                                                double* __restrict__ max_map,
@@ -250,29 +325,6 @@ __global__ __launch_bounds__(256) void k_compute_dosage(const double* __restrict
     const double num = (double)scaled_power * map[i];
     const float den = area[i] * (float)photons_per_light;
     dosage[i] = (float)(num / (double)den);
-}
-
-// shade.cl:4-21
-__device__ __forceinline__ void heatmap(float intensity, float& r, float& g, float& b)
-{
-    const float minDosageColor = 0.5f;
-    const float upperHalfColor = 0.75f;   // 0.5f + (1.0 - 0.5f) / 2, exact
-    const float lowerHalfColor = 0.25f;   // 0.5f / 2.0f, exact
-    if (intensity > minDosageColor) {
-        if (intensity > upperHalfColor) {
-            r = 1.0f; g = (1.0f - intensity) / (1.0f - upperHalfColor); b = 0.0f;
-        } else {
-            r = (intensity - minDosageColor) / (upperHalfColor - minDosageColor);
-            g = 1.0f; b = 0.0f;
-        }
-    } else {
-        if (intensity > lowerHalfColor) {
-            r = 0.0f; g = 1.0f;
-            b = (minDosageColor - intensity) / (minDosageColor - lowerHalfColor);
-        } else {
-            r = 0.0f; g = intensity / lowerHalfColor; b = 1.0f;
-        }
-    }
 }
 
 // shade.cl:43-71
@@ -344,6 +396,31 @@ void launch_generate(const GenParams& p0, hipStream_t s)
     const unsigned prep_blocks = p.prep_recs ? blocks_for(p.prep_npairs, 256) : 0u;
     if (p.ray_blocks + prep_blocks == 0) return;
     hipLaunchKernelGGL(k_generate, dim3(p.ray_blocks + prep_blocks), dim3(256), 0, s, p);
+}
+
+void launch_generate_batch(const GenBatchParams& p, hipStream_t s)
+{
+    if (p.n <= 0 || p.count <= 0) return;
+    hipLaunchKernelGGL(k_generate_batch, dim3(blocks_for(p.n, 256), (unsigned)p.count), dim3(256), 0, s, p);
+}
+
+void launch_fold_planes(int32_t* planes, int32_t* folded, int32_t nplanes, int32_t replicas, int32_t T, hipStream_t s)
+{
+    if (nplanes <= 0 || T <= 0) return;
+    hipLaunchKernelGGL(k_fold_planes, dim3(blocks_for((int64_t)T * 4, 256), (unsigned)nplanes), dim3(256), 0, s, planes,
+                       folded, replicas, T);
+}
+
+void launch_replay_batch(const ReplayParams& p, hipStream_t s)
+{
+    if (p.count <= 0 || p.T <= 0) return;
+    hipLaunchKernelGGL(k_replay_batch, dim3(blocks_for((int64_t)p.T * 4, 256)), dim3(256), 0, s, p);
+}
+
+void launch_add_counts(int32_t* dst, const int32_t* src, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_add_counts, dim3(blocks_for(n, 256)), dim3(256), 0, s, dst, src, n);
 }
 
 void launch_scan_bins(uint32_t* hist, uint32_t* bin_start, int32_t nbins, hipStream_t s)

@@ -51,6 +51,10 @@ SYMBOLS = [
     ("uvrt_host_rt_read_dosage", None, [_vp, _vp, C.c_int, C.c_int]),
     ("uvrt_host_rt_ctx", _vp, [_vp]),
     ("uvrt_host_rt_set_shard", None, [_vp, C.c_int, C.c_int]),
+    ("uvrt_host_rt_compute_batched", None, [_vp, C.c_int]),
+    ("uvrt_host_rt_compute_batched_group", None, [C.POINTER(_vp), C.c_int, C.c_int]),
+    ("uvrt_host_rt_set_ray_range", None, [_vp, C.c_int, C.c_int]),
+    ("uvrt_host_rt_set_reduce_over_comm", None, [_vp, C.c_int]),
     ("uvrt_host_rt_lamp_count", C.c_int, [_vp]),
     ("uvrt_host_rt_get_lamp", None, [_vp, C.c_int, C.POINTER(C.c_float)]),
     ("uvrt_host_rt_set_lamps", None, [_vp, C.POINTER(C.c_float), C.c_int]),
@@ -212,6 +216,9 @@ class RayTracer:
     # headless additions
     def Sync(self): self._L.uvrt_host_rt_sync(self._h)
     def set_shard(self, rank, world): self._L.uvrt_host_rt_set_shard(self._h, int(rank), int(world))
+    def ComputeIterationsBatched(self, iterations): self._L.uvrt_host_rt_compute_batched(self._h, int(iterations))
+    def SetRayRange(self, rank, world): self._L.uvrt_host_rt_set_ray_range(self._h, int(rank), int(world))
+    def set_reduce_over_comm(self, on): self._L.uvrt_host_rt_set_reduce_over_comm(self._h, int(bool(on)))
 
     def lamps(self):
         out = []
@@ -231,6 +238,12 @@ class RayTracer:
         out = np.empty(count, dtype=np.float32)
         self._L.uvrt_host_rt_read_dosage(self._h, out.ctypes.data_as(_vp), first, count)
         return out
+
+
+def compute_iterations_batched_group(rts, iterations):
+    """RayTracer::ComputeIterationsBatched over instances that share every launch by ray range (one process)."""
+    arr = (C.c_void_p * len(rts))(*[rt._h for rt in rts])
+    lib().uvrt_host_rt_compute_batched_group(arr, len(rts), int(iterations))
 
 
 class _BorrowedCtx(capi.Ctx):

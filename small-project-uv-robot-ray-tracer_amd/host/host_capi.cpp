@@ -3,6 +3,7 @@
 #include "raytracer.h"
 
 #include <cstring>
+#include <vector>
 
 using namespace Tmpl8;
 
@@ -80,6 +81,16 @@ void uvrt_host_rt_set_shard(void* r, int rank, int world)
     ((RayTracer*)r)->shardWorld = world;
     ((RayTracer*)r)->launchIndex = 0;
 }
+
+void uvrt_host_rt_compute_batched(void* r, int iterations) { ((RayTracer*)r)->ComputeIterationsBatched(iterations); }
+void uvrt_host_rt_compute_batched_group(void** rs, int n, int iterations)
+{
+    std::vector<RayTracer*> g;
+    for (int i = 0; i < n; ++i) g.push_back((RayTracer*)rs[i]);
+    RayTracer::ComputeIterationsBatched(g, iterations);
+}
+void uvrt_host_rt_set_ray_range(void* r, int rank, int world) { ((RayTracer*)r)->SetRayRange(rank, world); }
+void uvrt_host_rt_set_reduce_over_comm(void* r, int on) { ((RayTracer*)r)->reduceOverComm = on != 0; }
 
 int uvrt_host_rt_lamp_count(void* r) { return (int)((RayTracer*)r)->lightPositions.size(); }
 void uvrt_host_rt_get_lamp(void* r, int i, float* xyd)

@@ -8,6 +8,7 @@
 
 #include "../../include/uvrt.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,11 @@ void check(int rc, const char* what)
 {
     if (rc == UVRT_OK) return;
     fprintf(stderr, "Fatal error in %s: %s\n", what, uvrt_last_error());
+    exit(1);
+}
+void fatal(const char* what)
+{
+    fprintf(stderr, "Fatal error: %s\n", what);
     exit(1);
 }
 
@@ -178,6 +184,78 @@ void RayTracer::ComputeSingleLightDosageMap(LightPos lightPos, int photonsPerLig
         check(uvrt_advance_seed(ctx, lp, lightLength), "advance_seed");
     }
     photonMapSize += photonsPerLight;                                   // :87
+}
+
+void RayTracer::SetRayRange(int rank, int world)
+{
+    // contiguous global-id ranges; the union over the ranks is [0, photonsPerLight)
+    const long long n = photonsPerLight, share = (n + world - 1) / world;
+    rangeFirst = std::min((long long)rank * share, n);
+    rangeCount = std::min(share, n - rangeFirst);
+}
+
+void RayTracer::ComputeIterationsBatched(int iterations)
+{
+    std::vector<RayTracer*> self{this};
+    ComputeIterationsBatched(self, iterations);
+}
+
+void RayTracer::ComputeIterationsBatched(const std::vector<RayTracer*>& group, int iterations)
+{
+    RayTracer* r0 = group[0];
+    const int L = (int)r0->lightPositions.size();
+    const long long total = (long long)iterations * L;
+    const int kMax = 64;                                  // launches per uvrt_trace_batch
+    std::vector<float> lamps((size_t)kMax * 3);
+    std::vector<uvrt_replay_op> ops((size_t)kMax);
+    std::vector<uvrt_ctx*> ctxs;
+    for (RayTracer* rt : group) ctxs.push_back(rt->ctx);
+    long long done = 0;
+    while (done < total) {
+        int cnt = (int)std::min<long long>(kMax, total - done);
+        if (cnt < total - done && cnt >= L) cnt -= (int)((done + cnt) % L);    // end on an iteration where one fits
+        for (RayTracer* rt : group) {
+            for (int j = 0; j < cnt; ++j) {
+                const int li = (int)((done + j) % L);
+                const LightPos& lp = rt->lightPositions[li];
+                lamps[3 * j + 0] = lp.position.x;                                // raytracer.cpp:77
+                lamps[3 * j + 1] = rt->mesh->floorHeight + rt->lightHeight;
+                lamps[3 * j + 2] = lp.position.y;
+                uvrt_replay_op& op = ops[j];
+                op.duration = lp.duration;                                       // :84
+                rt->photonMapSize += rt->photonsPerLight;                         // :87
+                ++rt->launchIndex;
+                op.shade = li == L - 1;                                          // myapp.cpp:160
+                if (rt->viewMode == maxpower) {                                  // raytracer.cpp:96-104
+                    op.which_map = UVRT_MAP_MAX;
+                    op.photons_per_light = rt->photonsPerLight;
+                    op.scaled_power = rt->lightIntensity * 100;
+                    op.min_value = rt->minPower;
+                } else {                                                         // :106-116
+                    op.which_map = UVRT_MAP_SUM;
+                    op.photons_per_light = rt->photonMapSize / (int)rt->lightPositions.size();
+                    op.scaled_power = rt->lightIntensity * 0.1f;
+                    op.min_value = rt->minDosage;
+                }
+                op.threshold_view = rt->thresholdView;
+                if (op.shade) {                                                  // myapp.cpp:162-163
+                    ++rt->currIterations;
+                    rt->progress = 100.0f * (float)rt->currIterations / (float)rt->maxIterations;
+                }
+            }
+            const long long n = rt->rangeCount < 0 ? rt->photonsPerLight : rt->rangeCount;
+            if (n > 0)
+                check(uvrt_trace_batch(rt->ctx, lamps.data(), rt->lightLength, cnt, rt->rangeFirst, n), "trace_batch");
+            else
+                fatal("ComputeIterationsBatched: an empty ray range (more ranks than photons)");
+        }
+        if (group.size() > 1) check(uvrt_reduce_batch_group(ctxs.data(), (int)ctxs.size()), "reduce_batch_group");
+        for (RayTracer* rt : group) {
+            if (group.size() == 1 && rt->reduceOverComm) check(uvrt_reduce_batch(rt->ctx), "reduce_batch");
+            check(uvrt_replay_batch(rt->ctx, ops.data(), cnt, rt->mesh->triangleCount), "replay_batch");
+        }
+        done += cnt;
+    }
 }
 
 void RayTracer::Shade()                                      // raytracer.cpp:93-120

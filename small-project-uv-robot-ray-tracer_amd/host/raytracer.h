@@ -78,6 +78,18 @@ public:
     // photonMap with SUM and maxPhotonMap with MAX (both exact) before Shade().
     int shardRank = 0, shardWorld = 1;
     long long launchIndex = 0;
+    // Batched computation (include/uvrt.h "batched tracing"): what MyApp::Tick does over `iterations`
+    // frames (myapp.cpp:156-163: ComputeDosageMap(); Shade(); currIterations++), with all launches of a
+    // batch traced first and accumulate + Shade replayed per launch afterwards: same maps, dose and colours
+    // bit for bit, far fewer kernel launches.  `group`: instances that together trace every launch by
+    // global-id range (rangeFirst / rangeCount; BASELINE configs[3] "pixel tiles") inside ONE process --
+    // their planes are summed by uvrt_reduce_batch_group; an instance whose context holds a communicator
+    // (one process per GPU, uvrt_comm_init_rank) reduces over it.
+    void ComputeIterationsBatched(int iterations);
+    static void ComputeIterationsBatched(const std::vector<RayTracer*>& group, int iterations);
+    long long rangeFirst = 0, rangeCount = -1;      // -1: the whole launch
+    bool reduceOverComm = false;                    // ctx has a communicator: all-reduce the planes of every batch
+    void SetRayRange(int rank, int world);          // contiguous share of [0, photonsPerLight) for rank of world
     // The reference never reads the dose back; the headless build does.
     void ReadDosage(float* out, int first, int count);
     void Sync();                        // clFinish(Kernel::GetQueue()), myapp.cpp:165

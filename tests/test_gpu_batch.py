@@ -1,0 +1,209 @@
+"""GPU: batched tracing (include/uvrt.h uvrt_trace_batch / uvrt_replay_batch / uvrt_reduce_batch*) against the
+per-launch sequence of the reference's host loop (raytracer.cpp:66-88, myapp.cpp:156-163) and the oracle:
+per-launch counts, f64 maps, dose, colours and the SEED chain must be bit-identical; ray-range sharding with
+ONE reduction per batch must equal the unsharded computation."""
+import numpy as np
+import pytest
+
+from conftest import GLB, ROUTE
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def bits64(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def lamp_pos(orc, oscene, oroute, k):
+    comp = orc.Computation(oscene, oroute["lamps"], 1 << 16, oroute["lightHeight"], oroute["lightLength"],
+                           oroute["lightIntensity"])
+    return tuple(float(x) for x in comp.lamp_world_pos(oroute["lamps"][k]))
+
+
+def make_ops(pkg, durations, shade_at, ppl):
+    ops = np.zeros(len(durations), dtype=pkg.capi.REPLAY_OP_DT)
+    for k, d in enumerate(durations):
+        ops[k] = (d, 1 if k in shade_at else 0, shade_at.get(k, 0), ppl * (k + 1), 44.0197, 100.0, k & 1)
+    return ops
+
+
+@pytest.mark.parametrize("n", [100001, 65536])
+def test_batch_equals_the_per_launch_sequence_and_the_oracle(pkg, orc, oscene, oroute, n):
+    """Five launches from three lamps (two lamp columns repeat, so launches are regrouped internally),
+    a ray count that is not a multiple of 64; replay with a Shade after launches 2 (max map) and 4 (sum)."""
+    length = oroute["lightLength"]
+    order = [0, 5, 0, 9, 5]
+    lamps = [lamp_pos(orc, oscene, oroute, k) for k in order]
+    durations = [60.0, 30.0, 45.0, 10.0, 25.0]
+    shade_at = {2: 1, 4: 0}
+    ops = make_ops(pkg, durations, shade_at, n)
+    a = pkg.capi.Ctx(0)
+    b = pkg.capi.Ctx(0)
+    try:
+        for c in (a, b):
+            c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+            c.resize_rays(n)
+            c.reset(True)
+            c.seed = 0x1234
+        # per-launch sequence
+        per_launch = []
+        snap = {}
+        for k, lp in enumerate(lamps):
+            a.generate(lp, length, 0, n)
+            a.extend(n)
+            per_launch.append(a.read_counts())
+            a.accumulate(durations[k])
+            if k in shade_at:
+                a.shade(int(ops[k]["which_map"]), int(ops[k]["photons_per_light"]), float(ops[k]["scaled_power"]),
+                        float(ops[k]["min_value"]), int(ops[k]["threshold_view"]))
+                snap[k] = (a.read_dosage(), a.read_color())
+        # batch
+        b.trace_batch(lamps, length, 0, n)
+        assert b.seed == a.seed
+        for k in range(len(lamps)):
+            assert np.array_equal(b.read_batch_counts(k), per_launch[k]), k
+        b.replay_batch(ops)
+        assert np.array_equal(bits64(b.read_photon_map(0)), bits64(a.read_photon_map(0)))
+        assert np.array_equal(bits64(b.read_photon_map(1)), bits64(a.read_photon_map(1)))
+        assert np.array_equal(bits(b.read_dosage()), bits(snap[4][0])) and np.array_equal(bits(b.read_color()), bits(snap[4][1]))
+        # the oracle on launch 3
+        rays, _ = orc.generate(0, n, lamps[3], length, pkg.capi.seed_next(lamps[2], length, pkg.capi.seed_next(
+            lamps[1], length, pkg.capi.seed_next(lamps[0], length, 0x1234))))
+        temp = np.zeros(oscene.T, dtype=np.int32)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        assert np.array_equal(temp, per_launch[3]) and temp.sum() > 0.5 * n
+        # a second batch on the same context, replayed WITHOUT the fold (the un-folded replica path)
+        b.trace_batch(lamps[:2], length, 7, 1000)
+        b.replay_batch(make_ops(pkg, durations[:2], {1: 0}, 1000))
+        a.generate(lamps[0], length, 7, 1000); a.extend(1000); a.accumulate(durations[0])
+        a.generate(lamps[1], length, 7, 1000); a.extend(1000); a.accumulate(durations[1])
+        assert np.array_equal(bits64(b.read_photon_map(0)), bits64(a.read_photon_map(0)))
+        assert b.seed == a.seed
+    finally:
+        a.close()
+        b.close()
+
+
+def test_batch_call_order_errors_and_reset(pkg, orc, oscene, oroute):
+    c = pkg.capi.Ctx(0)
+    try:
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        lp = lamp_pos(orc, oscene, oroute, 0)
+        with pytest.raises(pkg.capi.UvrtError, match="no traced batch"):
+            c.replay_batch(make_ops(pkg, [1.0], {}, 10))
+        c.trace_batch([lp], 1.0, 0, 5000)
+        with pytest.raises(pkg.capi.UvrtError, match="not been replayed"):
+            c.trace_batch([lp], 1.0, 0, 5000)
+        with pytest.raises(pkg.capi.UvrtError, match="2 operations"):
+            c.replay_batch(make_ops(pkg, [1.0, 2.0], {}, 10))
+        c.reset(True)                      # drops the traced batch
+        c.trace_batch([lp], 1.0, 0, 5000)
+        cnt = c.read_batch_counts(0)
+        c.replay_batch(make_ops(pkg, [2.0], {}, 5000))
+        assert np.array_equal(c.read_photon_map(0), cnt.astype(np.float64) * 2.0) and cnt.sum() > 2000
+        with pytest.raises(pkg.capi.UvrtError, match=r"\[1,64\]"):
+            c.trace_batch([lp] * 65, 1.0, 0, 100)
+        with pytest.raises(pkg.capi.UvrtError, match="no communicator"):
+            c.trace_batch([lp], 1.0, 0, 100)
+            c.reduce_batch()
+    finally:
+        c.close()
+
+
+def _host_rt(pkg, photons, lamps_n, view):
+    from uvrt_amd import host
+    rt = host.RayTracer(GLB, ROUTE, device=0)
+    rt.set_lamps(rt.lamps()[:lamps_n])
+    rt.photonCount = photons
+    rt.viewMode = view
+    rt.thresholdView = view == host.VIEW_MAXPOWER
+    return rt
+
+
+@pytest.mark.parametrize("lamps_n,iterations,photons,view", [(3, 3, 180000, 0), (12, 6, 120000, 1), (1, 8, 921600, 0)])
+def test_batched_raytracer_equals_the_host_loop(pkg, lamps_n, iterations, photons, view):
+    """RayTracer::ComputeIterationsBatched against ComputeDosageMap(); Shade(); per iteration (myapp.cpp:
+    156-163): 12 lamps x 6 iterations = 72 launches spans two batches; 1 lamp x 8 x 921 600 is the shape
+    of BASELINE configs[1] doubled."""
+    a = _host_rt(pkg, photons, lamps_n, view)
+    b = _host_rt(pkg, photons, lamps_n, view)
+    try:
+        a.maxIterations = b.maxIterations = iterations
+        a.ResetDosageMap()
+        for _ in range(iterations):
+            a.ComputeDosageMap()
+            a.Shade()
+            a.currIterations = a.currIterations + 1
+        b.ResetDosageMap()
+        b.ComputeIterationsBatched(iterations)
+        assert b.photonMapSize == a.photonMapSize and b.currIterations == a.currIterations == iterations
+        assert np.array_equal(bits(b.read_dosage()), bits(a.read_dosage()))
+        assert np.array_equal(bits(b.ctx.read_color()), bits(a.ctx.read_color()))
+        for w in (0, 1):
+            assert np.array_equal(bits64(b.ctx.read_photon_map(w)), bits64(a.ctx.read_photon_map(w)))
+        assert a.ctx.seed == b.ctx.seed and a.read_dosage().any()
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ray_range_shards_with_one_reduction_per_batch_equal_the_whole(pkg, world):
+    """BASELINE configs[3] on one device: `world` instances each trace their global-id range of every
+    launch into private planes, ONE sum of the planes per batch (uvrt_reduce_batch_group: contexts of one
+    device), then every instance replays accumulate + Shade -- all must hold the unsharded dose bits."""
+    from uvrt_amd import host
+    lamps_n, iterations, photons = 2, 4, 200002
+    one = _host_rt(pkg, photons, lamps_n, 0)
+    shards = [_host_rt(pkg, photons, lamps_n, 0) for _ in range(world)]
+    try:
+        one.ResetDosageMap()
+        one.ComputeIterationsBatched(iterations)
+        want = one.read_dosage()
+        for r, rt in enumerate(shards):
+            rt.ResetDosageMap()
+            rt.SetRayRange(r, world)
+        host.compute_iterations_batched_group(shards, iterations)
+        for rt in shards:
+            assert np.array_equal(bits(rt.read_dosage()), bits(want))
+            assert np.array_equal(bits64(rt.ctx.read_photon_map(1)), bits64(one.ctx.read_photon_map(1)))
+            assert rt.ctx.seed == one.ctx.seed
+        assert want.any()
+    finally:
+        one.close()
+        for rt in shards:
+            rt.close()
+
+
+def test_rccl_all_reduce_of_the_planes_single_rank_communicator(pkg, orc, oscene, oroute):
+    """The native collective (librccl opened by the library, ncclCommInitRank + ncclAllReduce(int32) on the
+    context's stream) with the world the box allows: one rank.  The planes must come back unchanged and the
+    replay must equal the un-reduced one; librccl must really be mapped into the process."""
+    lamps = [lamp_pos(orc, oscene, oroute, k) for k in (0, 1)]
+    n = 150000
+    a = pkg.capi.Ctx(0)
+    b = pkg.capi.Ctx(0)
+    try:
+        for c in (a, b):
+            c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+            c.reset(True)
+        b.comm_init_rank(pkg.capi.comm_unique_id(), 0, 1)
+        assert "librccl" in open("/proc/self/maps").read()
+        ops = make_ops(pkg, [60.0, 20.0], {1: 0}, n)
+        a.trace_batch(lamps, 1.0, 0, n)
+        want = [a.read_batch_counts(k) for k in range(2)]
+        a.replay_batch(ops)
+        b.trace_batch(lamps, 1.0, 0, n)
+        b.reduce_batch()
+        for k in range(2):
+            assert np.array_equal(b.read_batch_counts(k), want[k])
+        b.replay_batch(ops)
+        assert np.array_equal(bits(a.read_dosage()), bits(b.read_dosage())) and a.read_dosage().any()
+        b.comm_destroy()
+    finally:
+        a.close()
+        b.close()
