@@ -4,25 +4,26 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], mapped as SURVEY.md section 0 prescribes): rooms/C046_1.glb
-is absent from the reference checkout, so its stand-in is the reference's only shipped scene,
-testroomopt.glb (44 866 triangles vs 46 252); "1920x1080" = 2 073 600 photons per lamp launch;
-"8-bounce" = 8 waves of the reference's one-segment photon pass (the reference has no bounces);
-lamp 0 of positions/lange_route.xml; SEED_0 = 0.
+Workload (BASELINE.json configs[2] at N = 1, configs[3] at N > 1, mapped as SURVEY.md section 0 prescribes):
+rooms/C046_1.glb is absent from the reference checkout, so its stand-in is the reference's only shipped scene,
+testroomopt.glb (44 866 triangles vs 46 252); "1920x1080" = 2 073 600 photons per lamp launch; "8-bounce" =
+8 waves (iterations) of the reference's one-segment photon pass (the reference has no bounces); lamp 0 of
+positions/lange_route.xml; SEED_0 = 0.  `--scene soup:T` swaps in a synthetic T-triangle scene that does not
+fit in L2.
 
-One STEP = one whole computation by the reference's own host loop (RayTracer, myapp.cpp:156-175):
-ResetDosageMap, then per wave generate -> extend -> accumulate and Shade (computeDosage +
-dosageToColor), then -- with N > 1 -- the one reduction of the per-triangle maps over RCCL,
-a final Shade and a sync.  Inputs (scene, BVH) are resident in HBM before the timed region.
+One STEP = one whole computation: ResetDosageMap, then per wave generate -> extend -> accumulate and Shade
+(computeDosage + dosageToColor), then a sync.  Inputs (scene, BVH) are resident in HBM before the timed region.
+`--mode loop` (default at N = 1) is the reference's host loop call by call (myapp.cpp:156-163) with the
+library's two-stream launch pipelining; `--mode batched` runs it as RayTracer::ComputeIterationsBatched
+(include/uvrt.h "batched tracing": the waves traced first in fused launches of a few waves each, then
+accumulate + Shade replayed per wave: the same arithmetic, the same bits).  Both are timed at N = 1; `value`
+is the selected mode's, the other one is reported under `other_modes`.
 
-The library pipelines consecutive launches over two HIP streams (include/uvrt.h uvrt_set_pipeline;
---no-pipeline turns it off), so inside the timed region the extend kernels of neighbouring waves
-overlap and an event-bracketed kernel duration is not a kernel cost.  The `roofline` object is
-therefore measured in a separate pass right after the timed region: the same step with the
-pipelining off, HIP events around every uvrt_extend on its stream (`timing_pass`).
-
-Scaling is WEAK: every GPU traces 8 waves; with N GPUs the computation has 8*N waves (launch k
-runs on rank k % N, raytracer.h shardRank/shardWorld), so `value` = 8*N*2 073 600 rays / time.
+N > 1 (one process per GPU): STRONG scaling is the headline -- BASELINE configs[3]: every launch is split by
+global-id range over the ranks ("pixel tiles"), each rank deposits into private int32 planes, ONE RCCL
+all-reduce of the planes per computation (native: uvrt_reduce_batch), then every rank replays accumulate +
+Shade; the dose is bit-identical to one GPU.  The WEAK figure (configs[4]: whole launches dealt to ranks, 8
+waves per GPU, one SUM/MAX reduction of the f64 maps) is measured in the same run and reported beside it.
 """
 from __future__ import annotations
 
@@ -31,6 +32,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -56,16 +58,16 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("UVRT_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(glb, route_xml, waves, photons, flavour=0):
-    """The oracle (CPU restatement of the reference kernels, OpenMP on all host cores) timed on
-    the same workload: `waves` launches of `photons` photons from lamp 0.  Also returns the
-    traversal census that prices the algorithmic bytes per ray."""
+def cpu_baseline(scene, route, waves, photons, flavour=0, budget_s=25.0):
+    """The oracle (CPU restatement of the reference kernels, OpenMP on the host's cores) timed on the same
+    workload: `waves` launches of `photons` photons from lamp 0, cut short after about `budget_s` seconds of CPU
+    work.  Also returns the traversal census that prices the algorithmic bytes per ray and, when
+    all waves were run, the reference dose."""
     import __graft_entry__ as g
     orc = g.load_oracle()
     import numpy as np
     orc.set_flavour(flavour)
-    s = orc.Scene(glb)
-    r = orc.load_route(route_xml)
+    s, r = scene, route
     cores = host_cores()
     c = orc.Computation(s, r["lamps"][:1], photons, r["lightHeight"], r["lightLength"], r["lightIntensity"],
                         nthreads=cores)
@@ -74,7 +76,8 @@ def cpu_baseline(glb, route_xml, waves, photons, flavour=0):
     lamp = r["lamps"][0]
     lp = c.lamp_world_pos(lamp)
     t0 = time.time()
-    for _ in range(waves):
+    done = 0
+    for w in range(waves):
         a = time.time()
         rays, c.SEED = orc.generate(0, photons, lp, c.lightLength, c.SEED)
         b = time.time()
@@ -85,12 +88,15 @@ def cpu_baseline(glb, route_xml, waves, photons, flavour=0):
         c.stats.append(st)
         t_gen += b - a
         t_ext += d - b
-    dose = c.dose()
+        done += 1
+        if time.time() - t0 > budget_s and w + 1 < waves:
+            break
     total = time.time() - t0
+    dose = c.dose() if done == waves else None
     tot = {k: sum(x[k] for x in c.stats) for k in ("rays", "aabb_tests", "tri_tests", "hits", "node_visits")}
-    # The reference's own cl/extend.cl, compiled unmodified for gfx950 (oracle/_ref), timed on this
-    # GPU on the last wave's rays: the closest thing to "the reference OpenCL path in the same run"
-    # (no OpenCL CPU device exists in ROCm).
+    # The reference's own cl/extend.cl, compiled unmodified for gfx950 (oracle/_ref), timed on this GPU on the
+    # last wave's rays: the closest thing to "the reference OpenCL path in the same run" (no OpenCL CPU device
+    # exists in ROCm).
     ref_gpu = None
     try:
         if photons % 256 == 0 and orc.refgpu() is not None:
@@ -103,13 +109,32 @@ def cpu_baseline(glb, route_xml, waves, photons, flavour=0):
                        "triID_equal_to_oracle": float((rr["triID"] == rays["triID"]).mean())}
     except Exception as e:      # reporting only
         ref_gpu = {"error": str(e)[:200]}
+    orc.set_flavour(0)
     return {
         "reference_extend_cl_on_this_gpu": ref_gpu,
-        "value": waves * photons / total / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-        "sample": "%d waves x %d photons, lamp 0 (the full step); generate is serial (defines the SEED "
+        "value": done * photons / total / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "sample": "%d of the step's %d waves x %d photons, lamp 0; generate is serial (defines the SEED "
                   "semantics), extend uses %d OpenMP threads; extend-only %.2f Mray/s"
-                  % (waves, photons, cores, waves * photons / t_ext / 1e6),
+                  % (done, waves, photons, cores, done * photons / t_ext / 1e6),
     }, tot, dose
+
+
+def soup_triangles(T, seed=1):
+    """A synthetic scene that does not fit in L2: T small random triangles filling the test room's bounding box."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lo = np.array([-1.68, -1.44, -3.73], dtype=np.float32)
+    hi = np.array([1.63, 1.31, 5.56], dtype=np.float32)
+    c = rng.uniform(lo, hi, (T, 3)).astype(np.float32)
+    size = np.float32(0.5 * (float(np.prod(hi - lo)) / T) ** (1.0 / 3.0))
+    tris = np.zeros((T, 16), dtype=np.float32)
+    for k in range(3):
+        tris[:, 4 * k:4 * k + 3] = c + rng.uniform(-size, size, (T, 3)).astype(np.float32)
+    return tris
+
+
+class _Scene:
+    pass
 
 
 def main():
@@ -118,13 +143,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--photons", type=int, default=PHOTONS)
-    ap.add_argument("--waves", type=int, default=WAVES, help="waves (iterations) per GPU")
+    ap.add_argument("--waves", type=int, default=WAVES, help="waves (iterations) of the computation")
+    ap.add_argument("--mode", choices=["batched", "loop"], default=None,
+                    help="N = 1: loop (default) = the reference's host loop call by call; batched = RayTracer::"
+                         "ComputeIterationsBatched.  N > 1 always runs the batched, sharded computation")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1 headline: strong (default, BASELINE configs[3]: launches split by global-id range, one "
+                         "int32 all-reduce of the count planes per computation) or weak (configs[4]: whole launches dealt "
+                         "to ranks, 8 waves per GPU); the other one is measured too and reported beside it")
+    ap.add_argument("--scene", default=None, help="a .glb file, or soup:T for a synthetic T-triangle scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: launches do not overlap")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): 8 waves per GPU, launches dealt to ranks, one SUM/MAX reduce per step; "
-                         "strong: BASELINE configs[3] -- the same 8 waves split by global-id range over the ranks "
-                         "('pixel tiles'), int32 count all-reduce per launch")
     ap.add_argument("--sort-bits", type=int, default=None)
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--flavour", type=int, default=0, choices=[0, 1],
@@ -146,8 +175,12 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if world > 1 and args.mode == "loop":
+        raise SystemExit("--mode loop is a single-GPU mode (N > 1 runs the sharded batched computation)")
+    if args.mode is None:
+        args.mode = "loop" if world == 1 else "batched"
     ndev = torch.cuda.device_count()
-    rehearsal = world > ndev          # more ranks than GPUs: ranks share devices, collective over gloo
+    rehearsal = world > ndev          # more ranks than GPUs: ranks share devices, collectives over gloo
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -157,24 +190,36 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    coll_device = "cpu" if rehearsal else device
 
     import __graft_entry__ as g
     g.load_package()
-    from uvrt_amd import host, sharding
+    from uvrt_amd import capi, host, sharding
 
     glb = os.path.join(ROOT, "tests", "golden", "testroomopt.glb")
     route_xml = os.path.join(ROOT, "tests", "golden", "lange_route.xml")
+    scene_label = "testroomopt.glb (stand-in for the absent rooms/C046_1.glb)"
+    oscene = None
+    if args.scene and args.scene.startswith("soup:"):
+        T_soup = int(args.scene[5:])
+        mesh = host.Mesh(tris=soup_triangles(T_soup))     # BVH by the native builder (host/bvh.cpp)
+        rt = host.RayTracer(None, route_xml, device=dev_index, mesh=mesh)
+        scene_label = "synthetic soup of %d triangles in the test room's box (beyond L2)" % T_soup
+        oscene = _Scene()
+        oscene.tris, oscene.nodes, oscene.triIdx, oscene.T = mesh.tris(), mesh.nodes(), mesh.triIdx(), T_soup
+        oscene.floorHeight = np.float32(mesh.floorHeight)
+    else:
+        if args.scene:
+            glb = args.scene
+            scene_label = os.path.basename(glb)
+        rt = host.RayTracer(glb, route_xml, device=dev_index)
+    default_config = (args.scene is None and args.photons == PHOTONS and args.waves == WAVES)
 
-    # ---- product path: native loader + BVH + RayTracer on the HIP kernels -----------------
-    rt = host.RayTracer(glb, route_xml, device=dev_index)
     rt.set_lamps(rt.lamps()[:1])              # lamp 0
     rt.photonCount = args.photons
-    strong = args.scaling == "strong" and world > 1
-    rt.maxIterations = args.waves if strong else args.waves * world
-    rt.set_shard(0, 1) if strong else rt.set_shard(rank, world)
-    # One real (non-default) torch stream carries BOTH the uvrt kernels and the collective, so the
-    # reduction is ordered after the last accumulate and before the final Shade without host syncs.
-    # (torch's default stream has handle 0, which uvrt_set_stream reads as "use your own stream".)
+    rt.maxIterations = args.waves
+    # One real (non-default) torch stream carries BOTH the uvrt kernels and any torch collective, so reductions
+    # are ordered after the last deposit and before the replay without host syncs.
     stream = torch.cuda.Stream(device=device)
     assert stream.cuda_stream != 0
     rt.ctx.set_stream(stream.cuda_stream)
@@ -186,51 +231,64 @@ def main():
     if args.no_pipeline:
         rt.ctx.set_pipeline(False)
     rt.ctx.set_flavour(args.flavour)
-    reducer = sharding.MapReducer(rt.ctx, device) if (world > 1 and not strong) else None
+    n_launch = rt.photonsPerLight
+    lamp = rt.lamps()[0]
+    lp = (lamp[0], float(np.float32(np.float32(rt.mesh.floorHeight) + np.float32(rt.lightHeight))), lamp[1])
 
-    if strong:
-        # ray-range sharding of every launch: rank r generates and traces global ids
-        # [r*n/world, (r+1)*n/world) (the global id feeds the seed, so the union is the unsharded
-        # launch), the int32 per-triangle counts are summed over ranks, then every rank accumulates.
-        n_launch = rt.photonsPerLight
-        share = (n_launch + world - 1) // world
-        first = min(rank * share, n_launch)
-        mine = min(share, n_launch - first)
-        lamp = rt.lamps()[0]
-        lp = (lamp[0], float(np.float32(np.float32(rt.mesh.floorHeight) + np.float32(rt.lightHeight))), lamp[1])
-        rt.ctx.set_pipeline(False)            # the count buffer is reduced in place after every launch:
-        counts_t = sharding.wrap_array(rt.ctx, 2, device, "<i4")   # one buffer set, one stream
+    # ---- the sharded (strong) computation: ray ranges + one collective per batch ---------------------------
+    native_comm = False
+    if world > 1 and not rehearsal:
+        ids = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        rt.ctx.comm_init_rank(ids[0], rank, world)
+        native_comm = True
+    share = (n_launch + world - 1) // world
+    first = min(rank * share, n_launch)
+    mine = min(share, n_launch - first)
 
-        def step():
-            rt.ctx.seed = 0
-            rt.ResetDosageMap()
-            for _ in range(args.waves):
-                rt.ctx.generate(lp, rt.lightLength, first, mine)
-                rt.ctx.extend(mine)
-                rt.ctx.device_ptr(2)                     # folds the deposit replicas into counts[0:T]
-                dist.all_reduce(counts_t, op=dist.ReduceOp.SUM)
-                rt.ctx.accumulate(lamp[2])
-                rt.photonMapSize = rt.photonMapSize + n_launch
-                rt.Shade()
-                rt.currIterations = rt.currIterations + 1
-
-    def _weak_step():
+    def step_batched():
         rt.ctx.seed = 0                       # every step is the same computation (fresh-Init SEED)
         rt.ResetDosageMap()
-        rt.set_shard(rank, world)             # restart the global launch index
-        for it in range(rt.maxIterations):    # myapp.cpp:156-163
+        if world > 1 and rehearsal:
+            # ranks share a GPU: RCCL wants one rank per device, so the planes go through gloo (test path only)
+            ops = np.zeros(args.waves, dtype=capi.REPLAY_OP_DT)
+            for k in range(args.waves):
+                ops[k] = (lamp[2], 1, 0, (k + 1) * n_launch, float(np.float32(rt.lightIntensity) * np.float32(0.1)),
+                          rt.minDosage, 0)
+            rt.ctx.trace_batch([lp] * args.waves, rt.lightLength, first, mine)
+            planes = sharding.wrap_array(rt.ctx, 5, device, "<i4")
+            torch.cuda.current_stream().synchronize()
+            host_planes = planes.cpu()
+            dist.all_reduce(host_planes, op=dist.ReduceOp.SUM)
+            planes.copy_(host_planes)
+            rt.ctx.replay_batch(ops)
+            rt.photonMapSize = args.waves * n_launch
+            rt.currIterations = args.waves
+        else:
+            rt.ComputeIterationsBatched(args.waves)
+
+    def step_loop():
+        rt.ctx.seed = 0
+        rt.ResetDosageMap()
+        for _ in range(args.waves):           # myapp.cpp:156-163
             rt.ComputeDosageMap()
-            # one lamp => launch `it` belongs to rank it % world: every rank shades after each of ITS
-            # launches (the per-GPU work of the N = 1 step), not after the launches it skipped
-            if world == 1 or it % world == rank:
+            rt.Shade()
+            rt.currIterations = rt.currIterations + 1
+
+    reducer = [None]
+
+    def step_weak():
+        # whole launches dealt to ranks: 8 waves per GPU, launch k on rank k % world, one SUM/MAX of the maps
+        rt.ctx.seed = 0
+        rt.ResetDosageMap()
+        rt.set_shard(rank, world)
+        for it in range(args.waves * world):
+            rt.ComputeDosageMap()
+            if it % world == rank:
                 rt.Shade()
             rt.currIterations = rt.currIterations + 1
-        if reducer is not None:
-            reducer()
-            rt.Shade()
-
-    if not strong:
-        step = _weak_step
+        reducer[0]()
+        rt.Shade()
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -238,166 +296,236 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    rt.Sync()                                  # surfaces a traversal-stack overflow, if any
-    # the result of the TIMED region itself (the last of its steps), read before anything else runs
-    import zlib
-    dose_timed = rt.read_dosage()
-    crc_timed = "%08x" % zlib.crc32(dose_timed.tobytes())
-    # one computation on its own, bracketed by syncs (the reference syncs every iteration,
-    # myapp.cpp:165; `value` is the steady-state rate of back-to-back computations)
-    single_ms = []
-    for _ in range(max(1, min(5, args.steps))):
+    def timed(step, warmup, steps):
+        for _ in range(warmup):
+            step()
         sync_all()
-        t1 = time.perf_counter()
-        step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
         sync_all()
-        single_ms.append((time.perf_counter() - t1) * 1e3)
-    single_ms.sort()
-    single_ms = single_ms[len(single_ms) // 2]
-    # timing pass for the roofline: the same step, launches not overlapped, events around extend
-    timing_steps = max(1, min(3, args.steps))
-    rt.ctx.set_pipeline(False)
-    rt.ctx.set_timing(True)
-    rt.ctx.extend_time_ms()                    # drop anything recorded so far
-    for _ in range(timing_steps):
-        step()
-    sync_all()
-    ext_ms, ext_launches = rt.ctx.extend_time_ms()
-    rt.ctx.set_timing(False)
-    rt.ctx.set_pipeline(not args.no_pipeline and not strong)
-    rt.Sync()
+        el = time.perf_counter() - t0
+        rt.Sync()                              # surfaces a traversal-stack overflow, if any
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    rays_per_step = rt.maxIterations * rt.photonsPerLight
+    def crc(a):
+        return "%08x" % zlib.crc32(a.tobytes())
+
+    rays_per_step = args.waves * n_launch
+    other_modes = {}
+    weak = strong = None
+    single_ms = None
+    ext_ms = ext_launches = None
+    timing_steps = max(1, min(3, args.steps))
+
+    if world == 1:
+        headline = step_batched if args.mode == "batched" else step_loop
+        elapsed = timed(headline, args.warmup, args.steps)
+        # the result of the TIMED region itself (the last of its steps), read before anything else runs
+        dose_timed = rt.read_dosage()
+        # one computation on its own, bracketed by syncs (the reference syncs every iteration, myapp.cpp:165;
+        # `value` is the steady-state rate of back-to-back computations)
+        sm = []
+        for _ in range(max(1, min(5, args.steps))):
+            sync_all()
+            t1 = time.perf_counter()
+            headline()
+            sync_all()
+            sm.append((time.perf_counter() - t1) * 1e3)
+        sm.sort()
+        single_ms = sm[len(sm) // 2]
+        # the other mode, for comparison, and its dose
+        other = step_loop if args.mode == "batched" else step_batched
+        el_o = timed(other, args.warmup, args.steps)
+        other_modes["loop" if args.mode == "batched" else "batched"] = {
+            "value": round(rays_per_step * args.steps / el_o / 1e6, 2), "ms_per_step": round(el_o / args.steps * 1e3, 4),
+            "dose_crc32": crc(rt.read_dosage())}
+        # timing pass for the roofline: the headline step with HIP events around the extend launches on their
+        # stream (loop mode: launch pipelining off, so the kernels of neighbouring waves do not overlap)
+        if args.mode == "loop":
+            rt.ctx.set_pipeline(False)
+        rt.ctx.set_timing(True)
+        rt.ctx.extend_time_ms()                    # drop anything recorded so far
+        for _ in range(timing_steps):
+            headline()
+        sync_all()
+        ext_ms, ext_launches = rt.ctx.extend_time_ms()
+        rt.ctx.set_timing(False)
+        rt.ctx.set_pipeline(not args.no_pipeline)
+        rt.Sync()
+    else:
+        # strong: BASELINE configs[3]
+        rt.SetRayRange(rank, world)
+        rt.set_reduce_over_comm(native_comm)
+        el_s = timed(step_batched, args.warmup, args.steps)
+        dose_s = rt.read_dosage()
+        strong = {"value": round(rays_per_step * args.steps / el_s / 1e6, 2), "unit": "Mray/s",
+                  "ms_per_step": round(el_s / args.steps * 1e3, 4), "rays_per_step": rays_per_step, "scaling": "strong",
+                  "parallelism": "ray-range-sharded x%d, one int32 all-reduce of the count planes per computation (%s)"
+                                 % (world, "native RCCL, uvrt_reduce_batch" if native_comm else "REHEARSAL: ranks share a GPU, gloo"),
+                  "dose_crc32": crc(dose_s)}
+        # weak: configs[4], same run
+        rt.SetRayRange(0, 1)
+        rt.set_reduce_over_comm(False)
+        rt.maxIterations = args.waves * world
+        reducer[0] = sharding.MapReducer(rt.ctx, device)
+        el_w = timed(step_weak, args.warmup, args.steps)
+        dose_w = rt.read_dosage()
+        weak = {"value": round(args.waves * world * n_launch * args.steps / el_w / 1e6, 2), "unit": "Mray/s",
+                "ms_per_step": round(el_w / args.steps * 1e3, 4), "rays_per_step": args.waves * world * n_launch,
+                "scaling": "weak", "parallelism": "launch-sharded x%d, one f64 SUM + MAX all-reduce of the maps" % world,
+                "dose_crc32": crc(dose_w)}
+        if args.scaling == "weak":
+            elapsed, dose_timed, rays_per_step = el_w, dose_w, args.waves * world * n_launch
+        else:
+            elapsed, dose_timed = el_s, dose_s
+    crc_timed = crc(dose_timed)
     value = rays_per_step * args.steps / elapsed / 1e6
-    dose = rt.read_dosage()
+    dose_after = rt.read_dosage()
+
     ranks_agree = None
     if world > 1:
-        # after the reduction every rank must hold the same maps, hence the same dose bits
-        import zlib
-        h = torch.tensor([zlib.crc32(dose.tobytes()), int(round(float(rt.ctx.read_photon_map(0).sum()) / 60.0))],
-                         dtype=torch.int64, device=device)
+        h = torch.tensor([zlib.crc32(dose_timed.tobytes())], dtype=torch.int64, device=coll_device)
         hs = [torch.zeros_like(h) for _ in range(world)]
         dist.all_gather(hs, h)
         ranks_agree = all(bool((x == hs[0]).all()) for x in hs)
-        total_hits = int(hs[0][1].item())
 
     if rank == 0:
         # ---- CPU baseline + census (rank 0, N = 1 only) -----------------------------------
         cpu = None
         census = None
+        expected = None
+        golden_crc = os.path.join(ROOT, "tests", "golden", "bench_dose_crc.json")
+        if default_config and os.path.exists(golden_crc) and not (world > 1 and args.scaling == "weak"):
+            expected = json.load(open(golden_crc)).get("flavour%d" % args.flavour)
         if world == 1 and not args.no_cpu_baseline:
-            cpu, census, ref_dose = cpu_baseline(glb, route_xml, args.waves, args.photons, args.flavour)
-            same = np.array_equal(dose_timed.view(np.uint32), ref_dose.view(np.uint32))
-            cpu["gpu_dose_bit_identical"] = bool(same)
-            cpu["checked"] = "dose read right after the timed (pipelined) steps, before the timing pass"
-            if not same:
-                raise SystemExit("bench: the dose of the timed region differs from the oracle's")
-        if census is None and os.path.exists(census_path()) and args.photons == PHOTONS:
+            orc = g.load_oracle()
+            if oscene is None:
+                oscene = orc.Scene(glb)
+            cpu, census, ref_dose = cpu_baseline(oscene, orc.load_route(route_xml), args.waves, args.photons, args.flavour)
+            if ref_dose is not None:
+                same = np.array_equal(dose_timed.view(np.uint32), ref_dose.view(np.uint32))
+                cpu["gpu_dose_bit_identical"] = bool(same)
+                cpu["checked"] = "dose read right after the timed steps, before any other pass"
+                if not same:
+                    raise SystemExit("bench: the dose of the timed region differs from the oracle's")
+            else:
+                cpu["gpu_dose_bit_identical"] = None
+                cpu["checked"] = "the CPU sample was cut short of the full step: no dose comparison in this run"
+        if expected is not None and crc_timed != expected:
+            raise SystemExit("bench: dose CRC %s of the timed region differs from the committed %s" % (crc_timed, expected))
+        if census is None and os.path.exists(census_path()) and default_config:
             census = json.load(open(census_path()))["per_launch_avg"]
-            n_census = 1
-        else:
-            n_census = args.waves
+        kernel_name = "k_extend6<2,false,true,%s>" % ("true" if args.flavour else "false")
         roof = None
-        avg_ms = ext_ms / max(ext_launches, 1)
-        model_path = os.path.join(ROOT, "profiles", "extend_issue_model.json")
-        if os.path.exists(model_path):
-            # The binding resource, priced with the per-ray instruction / lookup / byte counts of the kernel
-            # (rocprofv3 PMC passes, deterministic per launch: profiles/extend_issue_model.json, made by
-            # tests/tools/issue_model.py) and the issue rates calibrated on this GPU type
-            # (tests/tools/valu_calib.hip, profiles/r02_valu_calibration.txt); the DURATION is this run's.
-            m = json.load(open(model_path))
-            k = m["constants"]
-            pr = m["per_ray"]
-            n_l = float(rt.photonsPerLight)
-            sec = avg_ms * 1e-3
-            scale = n_l / m["rays_per_launch"]
-            simd_cycles = k["simds"] * k["clock_hz"] * sec
-            cu_cycles = k["cus"] * k["clock_hz"] * sec
-            util = {
-                "valu_issue": pr["valu_issue_cycles"] * n_l / simd_cycles,
-                "salu_issue": pr["salu_insts"] * n_l / cu_cycles,
-                "l1_lookup": pr["l1_lane_lookups"] * n_l / (cu_cycles * k["l1_lookups_per_clk_per_cu"]),
-                "hbm": pr["hbm_bytes"] * n_l / sec / k["hbm_peak_bytes_per_s"],
-            }
-            bound = max(util, key=util.get)
-            vc = m["valu_issue_cycles"]
-            roof = {"bound": bound, "kernel": "k_extend6<2,false,true,%s>" % ("true" if args.flavour else "false"),
-                    "achieved": round(pr["valu_issue_cycles"] * n_l / sec / 1e9, 1),
-                    "peak": round(k["simds"] * k["clock_hz"] / 1e9, 1), "unit": "G VALU issue-cycles/s",
-                    "frac": round(util["valu_issue"], 4),
-                    "frac_bracket": [round(vc["lower"] * scale / simd_cycles, 4), round(vc["upper"] * scale / simd_cycles, 4)],
-                    "lane_utilisation": round(m["lane_utilisation"], 4),
-                    "useful_lane_frac": round(util["valu_issue"] * m["lane_utilisation"], 4),
-                    "utilisation_of_every_unit": {u: round(v, 4) for u, v in util.items()},
-                    "wave_time_waiting_on_memory": round(m["wave_wait_frac"], 3) if m.get("wave_wait_frac") else None,
-                    "traffic": round(pr["hbm_bytes"] * n_l),
-                    "traffic_is": "static: PMC FETCH_SIZE x 2 + WRITE_SIZE of %s (not collected in this run)" % m["source"],
-                    "rays_per_launch": rt.photonsPerLight, "avg_launch_ms": round(avg_ms, 4),
-                    "extend_mray_s": round(rt.photonsPerLight / avg_ms / 1e3, 1),
-                    "clock_assumed_ghz": k["clock_hz"] / 1e9,
-                    "timing_pass": "%d step(s) with launch pipelining off after the timed region; HIP events "
-                                   "around uvrt_extend on its stream" % timing_steps,
-                    "model": "profiles/extend_issue_model.json (%s)" % m.get("note", ""),
-                    "note": "no unit is saturated: the launch is latency-bound (waves spend about half their life in "
-                            "s_waitcnt on record fetches) with VALU issue the busiest unit; packed f32 saves "
-                            "instructions, not issue cycles (DESIGN.md 4)"}
-        if census is not None:
-            # secondary: SURVEY.md 8d's HBM-read figure (algorithmic bytes of the REFERENCE's layout, every node
-            # visit priced as a memory read) -- exceeds the peak because the scene is L2/LDS resident
-            n = float(census["rays"])
-            bytes_per_ray = (32.0 + 8.0 + 32.0 * (1.0 + census["aabb_tests"] / n)
-                             + 68.0 * census["tri_tests"] / n + 4.0 * census["hits"] / n)
-            achieved = bytes_per_ray * rt.photonsPerLight / (avg_ms * 1e-3) / 1e9
-            hbm_alg = {"algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "achieved_GBs": round(achieved, 1),
-                       "peak_GBs": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 4),
-                       "note": "SURVEY 8d bookkeeping only: > 1 because node visits are served by L2/LDS; measured HBM "
-                               "traffic is `traffic` above"}
-            if roof is None:
-                roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
-            roof["hbm_algorithmic"] = hbm_alg
+        if ext_launches:
+            avg_ms = ext_ms / max(ext_launches, 1)
+            rays_per_extend = rays_per_step * timing_steps / max(ext_launches, 1)
+            model_path = os.path.join(ROOT, "profiles", "extend_issue_model_%s.json" % args.mode)
+            if not os.path.exists(model_path):
+                model_path = os.path.join(ROOT, "profiles", "extend_issue_model.json")
+            if os.path.exists(model_path) and args.scene is None:
+                # The binding resource, priced with the per-ray instruction / lookup / byte counts of the kernel
+                # (rocprofv3 PMC passes, deterministic per launch; tests/tools/issue_model.py) and the issue rates
+                # calibrated on this GPU type (tests/tools/valu_calib.hip, profiles/r02_valu_calibration.txt);
+                # the DURATION is this run's.
+                m = json.load(open(model_path))
+                k = m["constants"]
+                pr = m["per_ray"]
+                sec = avg_ms * 1e-3
+                simd_cycles = k["simds"] * k["clock_hz"] * sec
+                cu_cycles = k["cus"] * k["clock_hz"] * sec
+                util = {
+                    "valu_issue": pr["valu_issue_cycles"] * rays_per_extend / simd_cycles,
+                    "salu_issue": pr["salu_insts"] * rays_per_extend / cu_cycles,
+                    "l1_lookup": pr["l1_lane_lookups"] * rays_per_extend / (cu_cycles * k["l1_lookups_per_clk_per_cu"]),
+                    "hbm": pr["hbm_bytes"] * rays_per_extend / sec / k["hbm_peak_bytes_per_s"],
+                }
+                bound = max(util, key=util.get)
+                vc = m["valu_issue_cycles"]
+                scale = rays_per_extend / m["rays_per_launch"]
+                roof = {"bound": bound, "kernel": kernel_name,
+                        "achieved": round(pr["valu_issue_cycles"] * rays_per_extend / sec / 1e9, 1),
+                        "peak": round(k["simds"] * k["clock_hz"] / 1e9, 1), "unit": "G VALU issue-cycles/s",
+                        "frac": round(util["valu_issue"], 4),
+                        "frac_bracket": [round(vc["lower"] * scale / simd_cycles, 4), round(vc["upper"] * scale / simd_cycles, 4)],
+                        "lane_utilisation": round(m["lane_utilisation"], 4),
+                        "useful_lane_frac": round(util["valu_issue"] * m["lane_utilisation"], 4),
+                        "utilisation_of_every_unit": {u: round(v, 4) for u, v in util.items()},
+                        "wave_time_waiting_on_memory": round(m["wave_wait_frac"], 3) if m.get("wave_wait_frac") else None,
+                        "traffic": round(pr["hbm_bytes"] * rays_per_extend),
+                        "traffic_is": "static: PMC FETCH_SIZE x 2 + WRITE_SIZE per launch of %s (not collected in this run)" % m["source"],
+                        "rays_per_launch": int(rays_per_extend), "avg_launch_ms": round(avg_ms, 4),
+                        "extend_mray_s": round(rays_per_extend / avg_ms / 1e3, 1),
+                        "clock_assumed_ghz": k["clock_hz"] / 1e9,
+                        "timing_pass": "%d step(s) after the timed region; HIP events around the extend launch on its stream" % timing_steps,
+                        "model": "%s (%s)" % (os.path.relpath(model_path, ROOT), m.get("note", "")),
+                        "note": "no unit is saturated: the launch is latency-bound (waves spend about half their life in "
+                                "s_waitcnt on record fetches) with VALU issue the busiest unit; packed f32 saves "
+                                "instructions, not issue cycles (DESIGN.md 4)"}
+            if census is not None:
+                # SURVEY.md 8d's HBM-read figure (algorithmic bytes of the REFERENCE's layout, every node visit
+                # priced as a memory read): secondary on the L2-resident room, primary on a scene beyond L2
+                n = float(census["rays"])
+                bytes_per_ray = (32.0 + 8.0 + 32.0 * (1.0 + census["aabb_tests"] / n)
+                                 + 68.0 * census["tri_tests"] / n + 4.0 * census["hits"] / n)
+                achieved = bytes_per_ray * rays_per_extend / (avg_ms * 1e-3) / 1e9
+                hbm_alg = {"algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "achieved_GBs": round(achieved, 1),
+                           "peak_GBs": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "note": "SURVEY 8d bookkeeping: every node visit priced as a memory read of the reference's "
+                                   "32-B nodes / 64-B triangles; exceeds the peak where the scene is L2/LDS resident"}
+                if roof is None:
+                    roof = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "rays_per_launch": int(rays_per_extend), "avg_launch_ms": round(avg_ms, 4),
+                            "extend_mray_s": round(rays_per_extend / avg_ms / 1e3, 1),
+                            "note": "algorithmic bytes (SURVEY 8d) over the measured launch duration; `traffic` needs a PMC "
+                                    "pass (tests/tools/pmc_extend.sh): DESIGN.md 6 has this scene's"}
+                roof["hbm_algorithmic"] = hbm_alg
+        if world > 1:
+            step_text = ("waves x (generate, extend, accumulate, shade), whole launches dealt to ranks, one f64 SUM + MAX "
+                         "all-reduce of the maps" if args.scaling == "weak" else
+                         "generate + extend of this rank's ray range of all waves, ONE int32 all-reduce of the count planes, "
+                         "accumulate + shade replayed per wave")
+            par = (strong if args.scaling == "strong" else weak)["parallelism"]
+        else:
+            step_text = ("generate + extend of all waves (batched), accumulate + shade replayed per wave" if args.mode == "batched"
+                         else "waves x (generate, extend, accumulate, shade)")
+            par = "1 GPU"
         out = {
             "metric": "Mray/s (extend+shade) on C046_1.glb 1920x1080x8-bounce", "value": round(value, 2),
             "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "testroomopt.glb (stand-in for the absent rooms/C046_1.glb), %d photons/launch "
-                                   "x %d waves per GPU, lamp 0 of lange_route.xml, SEED_0=0; step = reset + waves x "
-                                   "(generate, extend, accumulate, shade)%s + sync"
-                                   % (rt.photonsPerLight, args.waves, " + RCCL SUM/MAX of the per-triangle maps"
-                                      if world > 1 else ""),
-                       "triangles": rt.mesh.triangleCount, "rays_per_step": rays_per_step,
-                       "launch_pipelining": bool(not args.no_pipeline and not strong),
-                       "parallelism": "launch-sharded x%d" % world + (" (REHEARSAL: ranks share a GPU, gloo)" if rehearsal else "")},
+            "config": {"workload": "%s, %d photons/launch x %d waves%s, lamp 0 of lange_route.xml, SEED_0=0; step = reset + %s + sync"
+                                   % (scene_label, n_launch, args.waves, " per GPU" if (world > 1 and args.scaling == "weak") else "",
+                                      step_text),
+                       "triangles": rt.mesh.triangleCount, "rays_per_step": rays_per_step, "mode": args.mode,
+                       "launch_pipelining": bool(not args.no_pipeline), "flavour": args.flavour, "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,
+            "dose_crc32": crc_timed, "dose_crc32_expected": expected, "dose_crc32_after_all_passes": crc(dose_after),
+            "value_is": "steady-state throughput of back-to-back computations (one device sync after the last step)",
         }
-        out["dose_crc32"] = crc_timed
-        out["dose_crc32_after_timing_pass"] = "%08x" % zlib.crc32(dose.tobytes())
-        if out["dose_crc32"] != out["dose_crc32_after_timing_pass"]:
-            raise SystemExit("bench: pipelined and one-stream passes disagree (%s vs %s)"
-                             % (out["dose_crc32"], out["dose_crc32_after_timing_pass"]))
-        out["value_is"] = "steady-state throughput of back-to-back computations (no sync between steps)"
-        out["single_computation"] = {"ms": round(single_ms, 4), "mray_s": round(rays_per_step / single_ms / 1e3, 1),
-                                     "note": "one step bracketed by device syncs, median of %d" % max(1, min(5, args.steps))}
-        out["config"]["flavour"] = args.flavour
-        if world > 1:
-            out["multi_gpu_check"] = {"dose_identical_on_all_ranks": ranks_agree, "photons_deposited": total_hits,
-                                      "photons_traced": rays_per_step}
+        if world == 1:
+            if crc(dose_after) != crc_timed or any(v["dose_crc32"] != crc_timed for v in other_modes.values()):
+                raise SystemExit("bench: the passes disagree on the dose (%s / %s / %s)" % (crc_timed, other_modes, crc(dose_after)))
+            out["single_computation"] = {"ms": round(single_ms, 4), "mray_s": round(rays_per_step / single_ms / 1e3, 1),
+                                         "note": "one step bracketed by device syncs, median of %d" % max(1, min(5, args.steps))}
+            out["other_modes"] = other_modes
+        else:
+            out["multi_gpu_check"] = {"dose_identical_on_all_ranks": ranks_agree, "photons_traced": rays_per_step}
+            out["strong"] = strong
+            out["weak"] = weak
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if native_comm:
+            rt.ctx.comm_destroy()
         dist.destroy_process_group()
     rt.close()
 

@@ -186,6 +186,11 @@ int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
  * run live on the same GPU, bit for bit.  Everything else (slab test, traversal, deposit) is
  * common to both flavours. */
 int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
+/* Which node-pair records the traversal serves from LDS: 1 (default) = the 127 records the lamp's photons
+ * visit most, found on the device from a sample of the launch's own rays the first time a lamp position is
+ * seen (62-70 % of all inner-node visits on the test room); 0 = the first 127 in breadth-first order
+ * (31-40 %).  Only the order of records in memory changes; results never depend on it. */
+int uvrt_set_hot_records(uvrt_ctx* ctx, int32_t mode);
 /* Renumber the node-pair records of the default extend kernel: record i (breadth-first index of the
  * inner node, as uvrt_set_scene lays them out) moves to perm[i]; the first 127 records of the new
  * numbering are served from LDS.  Results do not depend on it.  NULL restores the breadth-first
@@ -221,7 +226,8 @@ int uvrt_read_photon_map(uvrt_ctx* ctx, int32_t which_map, double* out, int32_t 
                          int32_t count);
 /* raw device pointers of the per-triangle arrays, for zero-copy wrapping (e.g. as torch
  * tensors handed to an RCCL collective).  which: 0 photonMap f64[T], 1 maxPhotonMap f64[T],
- * 2 tempPhotonMap i32[T], 3 dosageMap f32[T], 4 colour f32[9T].
+ * 2 tempPhotonMap i32[T], 3 dosageMap f32[T], 4 colour f32[9T], 5 the folded planes i32[launches][T] of the
+ * traced batch (for a caller that brings its own collective; uvrt_reduce_batch is the native one).
  * The call is also the ordering point for external work on these arrays: it orders the context's
  * stream after every outstanding launch (with launch pipelining some sit on the library's second
  * stream) and makes the library's next work on the arrays wait for whatever the caller enqueues on

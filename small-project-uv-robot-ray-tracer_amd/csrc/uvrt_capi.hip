@@ -72,8 +72,7 @@ struct uvrt_ctx {
     // scene
     int32_t T = 0;
     DevBuf pairs, recs, perm, ltris, leaf_count, area;
-    bool have_perm = false;      // extend v6 record renumbering (uvrt_set_record_perm)
-    uint32_t perm_root = 0;
+    bool have_perm = false;      // the caller's own record renumbering (uvrt_set_record_perm)
     int32_t npairs = 0;
     uint32_t root_ref = REF_DONE;
     uint32_t top_pairs = 0;      // inner nodes of the first 7 tree levels (breadth-first prefix of `pairs`)
@@ -122,6 +121,14 @@ struct uvrt_ctx {
     DevBuf xrays[MAXL], xrecs[MAXL], xcounts[MAXL], xovf[MAXL];   // [0] unused: lane 0 has rays, recs, counts, ovf_stack
     bool xrecs_valid[MAXL] = {};
     float xrecs_ox[MAXL] = {}, xrecs_oz[MAXL] = {};
+
+    // Hot-record renumbering per lamp position (uvrt_hotset.hip): the records a lamp's photons visit most are
+    // the ones the traversal serves from LDS.  Built on the device the first time a lamp is seen.
+    struct HotEntry { float lamp[3]; DevBuf perm, hist; uint64_t stamp; hipEvent_t ready; };
+    std::vector<HotEntry> hot;
+    uint64_t hot_clock = 0;
+    int32_t hot_mode = 1;                 // uvrt_set_hot_records: 1 = automatic (default), 0 = breadth-first order
+    const uint32_t* lane_perm[MAXL] = {}; // renumbering of the current launch of each lane (set by uvrt_generate)
 
     // Batched tracing (uvrt_trace_batch): the rays of up to MAX_BATCH launches side by side, one count
     // "plane" (replicas x T ints) per launch, one per-launch record array per distinct lamp.
@@ -225,6 +232,52 @@ DevBuf& lane_rays(uvrt_ctx* c) { return c->lane ? c->xrays[c->lane] : c->rays; }
 DevBuf& lane_recs(uvrt_ctx* c) { return c->lane ? c->xrecs[c->lane] : c->recs; }
 DevBuf& lane_counts(uvrt_ctx* c) { return c->lane ? c->xcounts[c->lane] : c->counts; }
 DevBuf& lane_ovf(uvrt_ctx* c) { return c->lane ? c->xovf[c->lane] : c->ovf_stack; }
+
+// The record renumbering for a launch from `lamp`: the caller's own (uvrt_set_record_perm), the automatic
+// hot-record one (statistics + selection enqueued on `s` the first time the lamp is seen), or none.
+int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t seed_prev, uint32_t seed_next, int64_t n,
+                hipStream_t s, const uint32_t** out)
+{
+    *out = nullptr;
+    if (c->have_perm) { *out = c->perm.as<uint32_t>(); return UVRT_OK; }
+    if (c->hot_mode == 0 || c->npairs <= (int32_t)128 || c->root_ref >= REF_LEAF_BIT) return UVRT_OK;
+    ++c->hot_clock;
+    for (auto& h : c->hot)
+        if (memcmp(h.lamp, lamp, 12) == 0) {
+            h.stamp = c->hot_clock;
+            HIP_TRY(hipStreamWaitEvent(s, h.ready, 0));      // it may have been built on another lane's stream
+            *out = h.perm.as<uint32_t>();
+            return UVRT_OK;
+        }
+    uvrt_ctx::HotEntry* e = nullptr;
+    if (c->hot.size() < 64) {
+        c->hot.emplace_back();
+        e = &c->hot.back();
+        if (int rc = e->perm.ensure((size_t)c->npairs * 4, false, s)) { c->hot.pop_back(); return rc; }
+        if (int rc = e->hist.ensure((size_t)c->npairs * 4, true, s)) { e->perm.release(); c->hot.pop_back(); return rc; }
+        HIP_TRY(hipEventCreateWithFlags(&e->ready, hipEventDisableTiming));
+    } else {          // recycle the least recently used entry: nothing in flight may still read its renumbering
+        if (int rc = join_all(c)) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        e = &c->hot[0];
+        for (auto& h : c->hot) if (h.stamp < e->stamp) e = &h;
+    }
+    memcpy(e->lamp, lamp, 12);
+    e->stamp = c->hot_clock;
+    SceneDev sc;
+    sc.pairs = c->pairs.as<PairRec>();
+    sc.ltris = c->ltris.as<LeafTri>();
+    sc.leaf_count = c->leaf_count.as<uint32_t>();
+    sc.root_ref = c->root_ref;
+    sc.tri_count = c->T;
+    launch_visit_stats(sc, e->hist.as<uint32_t>(), lamp, light_length, seed_prev, seed_next, c->seed_mode,
+                       (int32_t)std::min<int64_t>(n, 32768), s);
+    launch_select_hot(e->hist.as<uint32_t>(), e->perm.as<uint32_t>(), c->npairs, 127, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ready, s));
+    *out = e->perm.as<uint32_t>();
+    return UVRT_OK;
+}
 
 // work-item 0's RNG walk of cl/generate.cl:13-39 on the host (strict f32/f64, same order)
 uint32_t host_wang_hash(uint32_t s)
@@ -333,6 +386,7 @@ void uvrt_destroy(uvrt_ctx* c)
     if (c->ev_mapfence) (void)hipEventDestroy(c->ev_mapfence);
     if (c->comm) uvrt_comm_destroy(c);
     for (DevBuf& b : c->b_recs) b.release();
+    for (auto& h : c->hot) { h.perm.release(); h.hist.release(); (void)hipEventDestroy(h.ready); }
     for (DevBuf* b : {&c->b_rays, &c->b_planes, &c->b_folded}) b->release();
     for (DevBuf* b : {&c->pairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
@@ -496,6 +550,9 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->have_perm = false;
     c->have_scene = true;
     c->scene_force_exact = tiny_bound || huge_vertex;
+    for (auto& h : c->hot) { h.perm.release(); h.hist.release(); (void)hipEventDestroy(h.ready); }     // statistics of the previous scene
+    c->hot.clear();
+    for (int l = 0; l < uvrt_ctx::MAXL; ++l) c->lane_perm[l] = nullptr;
     // a batch of the previous scene is void; its buffers are sized per scene
     c->b_count = 0;
     c->b_is_folded = false;
@@ -640,7 +697,13 @@ int uvrt_generate(uvrt_ctx* c, const float lp[3], float light_length, int64_t fi
     if (c->npairs > 0) {   // extend's per-launch records ride along in the same launch
         p.prep_pairs = c->pairs.as<PairRec>();
         p.prep_recs = lane_recs(c).as<float4>();
-        p.prep_perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
+        // the statistics always sample global ids [0, 32768) of the lamp (the kernel makes its own rays), whichever
+        // range of the launch this context traces; launches too small to repay them keep the breadth-first order
+        const uint32_t* pm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
+        if (!pm && n >= 16384)
+            if (int rc = launch_perm(c, lp, light_length, seed_prev, seed_next, 32768, ls, &pm)) return rc;
+        c->lane_perm[c->lane] = pm;
+        p.prep_perm = pm;
         p.prep_npairs = c->npairs;
     }
     launch_generate(p, ls);
@@ -707,8 +770,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.n = n;
     p.npairs = c->npairs;
     p.recs = lane_recs(c).p;
-    p.perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
-    p.perm_root = c->perm_root;
+    p.perm = c->have_perm ? c->perm.as<uint32_t>() : c->lane_perm[c->lane];
     {
         const bool valid = c->lane ? c->xrecs_valid[c->lane] : c->recs_valid;
         const float rox = c->lane ? c->xrecs_ox[c->lane] : c->recs_ox, roz = c->lane ? c->xrecs_oz[c->lane] : c->recs_oz;
@@ -810,7 +872,6 @@ int uvrt_set_record_perm(uvrt_ctx* c, const uint32_t* perm, int32_t n)
     if (int rc = c->perm.ensure((size_t)n * 4, false, c->stream)) return rc;
     HIP_TRY(hipMemcpyAsync(c->perm.p, perm, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->perm_root = perm[0];
     c->have_perm = true;
     return UVRT_OK;
 }
@@ -965,65 +1026,103 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     for (int l = 1; l < c->nlanes; ++l)
         if ((rc = c->xovf[l].ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream))) return rc;
 
-    gp.rays = c->b_rays.as<float4>();
-    gp.n_pad = n_pad;
-    gp.first_gid = first_gid;
-    gp.n = n;
-    gp.light_length = light_length;
-    gp.seed_mode = c->seed_mode;
-    gp.count = count;
-    launch_generate_batch(gp, c->stream);
-    HIP_TRY(hipGetLastError());
-    if (int rcf = mark_fence(c)) return rcf;         // the lanes' next work waits for the generate
-    const int lane_before = c->lane;
+    // Per-launch records of every lamp column on the main stream, then the launches in CHUNKS of a few planes:
+    // generate + fused extend of a chunk on one launch lane, chunks alternating over the lanes.  A chunk's rays
+    // (16 B each) are sized to stay in the Infinity Cache between the generate that writes them and the extend
+    // that reads them (a refill that has to go to HBM stalls its wave for microseconds), and the next chunk's
+    // generate and first waves run in the drain of the previous one.
+    const uint32_t* gperm[MAX_BATCH] = {};
     for (int g = 0; g < ngroups; ++g) {
-        c->lane = (c->pipeline && c->nlanes > 1) ? g % c->nlanes : 0;
-        hipStream_t ls;
-        if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }
-        launch_prepare_launch6(c->pairs.as<PairRec>(), c->b_recs[g].p, gx[g], gz[g], c->npairs,
-                               c->have_perm ? c->perm.as<uint32_t>() : nullptr, ls);
-        ExtendParams p;
-        memset(&p, 0, sizeof p);
-        p.scene.pairs = c->pairs.as<PairRec>();
-        p.scene.ltris = c->ltris.as<LeafTri>();
-        p.scene.leaf_count = c->leaf_count.as<uint32_t>();
-        p.scene.root_ref = c->root_ref;
-        p.scene.tri_count = c->T;
-        p.rays = c->b_rays.as<float4>() + (size_t)gfirst[g] * (size_t)n_pad;
-        {
-            const float ax = std::fabs(gx[g]), az = std::fabs(gz[g]);
-            const float tiny = 7.888609e-31f;   // 2^-100
-            p.force_exact = (c->scene_force_exact || (ax != 0.0f && ax < tiny) || (az != 0.0f && az < tiny) ||
-                             !(ax <= 1e9f) || !(az <= 1e9f) || (c->variant >= 500 && c->variant < 600)) ? 1 : 0;
+        const int ph = gfirst[g];          // the group's first launch lends its lamp and seeds to the statistics
+        const float gl[3] = {gp.lx[ph], gp.ly[ph], gp.lz[ph]};
+        gperm[g] = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
+        if (!gperm[g] && (int64_t)gsize[g] * n >= 16384)
+            if (int rcp = launch_perm(c, gl, light_length, gp.seed_prev[ph], gp.seed_next[ph], 32768, c->stream, &gperm[g])) return rcp;
+        launch_prepare_launch6(c->pairs.as<PairRec>(), c->b_recs[g].p, gx[g], gz[g], c->npairs, gperm[g], c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    if (int rcf = mark_fence(c)) return rcf;         // the lanes' next work waits for the records (and the reset before)
+    size_t chunk_bytes = (size_t)96 << 20;
+    if (const char* e = getenv("UVRT_BATCH_CHUNK_MB")) { const long v = atol(e); if (v > 0) chunk_bytes = (size_t)v << 20; }
+    const int per_chunk = (int)std::max<size_t>(1, chunk_bytes / ((size_t)n_pad * 16));
+    const int lane_before = c->lane;
+    int chunk_index = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        for (int k0 = 0; k0 < gsize[g]; k0 += per_chunk, ++chunk_index) {
+            const int kc = std::min(per_chunk, gsize[g] - k0), ph0 = gfirst[g] + k0;
+            c->lane = (c->pipeline && c->nlanes > 1) ? chunk_index % c->nlanes : 0;
+            hipStream_t ls;
+            if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }
+            GenBatchParams gq;
+            memset(&gq, 0, sizeof gq);
+            gq.rays = c->b_rays.as<float4>() + (size_t)ph0 * (size_t)n_pad;
+            gq.n_pad = n_pad;
+            gq.first_gid = first_gid;
+            gq.n = n;
+            gq.light_length = light_length;
+            gq.seed_mode = c->seed_mode;
+            gq.count = kc;
+            for (int j = 0; j < kc; ++j) {
+                gq.lx[j] = gp.lx[ph0 + j]; gq.ly[j] = gp.ly[ph0 + j]; gq.lz[j] = gp.lz[ph0 + j];
+                gq.seed_prev[j] = gp.seed_prev[ph0 + j]; gq.seed_next[j] = gp.seed_next[ph0 + j];
+            }
+            launch_generate_batch(gq, ls);
+            ExtendParams p;
+            memset(&p, 0, sizeof p);
+            p.scene.pairs = c->pairs.as<PairRec>();
+            p.scene.ltris = c->ltris.as<LeafTri>();
+            p.scene.leaf_count = c->leaf_count.as<uint32_t>();
+            p.scene.root_ref = c->root_ref;
+            p.scene.tri_count = c->T;
+            p.rays = gq.rays;
+            {
+                const float ax = std::fabs(gx[g]), az = std::fabs(gz[g]);
+                const float tiny = 7.888609e-31f;   // 2^-100
+                p.force_exact = (c->scene_force_exact || (ax != 0.0f && ax < tiny) || (az != 0.0f && az < tiny) ||
+                                 !(ax <= 1e9f) || !(az <= 1e9f) || (c->variant >= 500 && c->variant < 600)) ? 1 : 0;
+            }
+            p.ovf_stack = lane_ovf(c).as<uint32_t>();
+            p.ovf_capacity = lane_ovf(c).bytes / sizeof(uint32_t);
+            p.num_cus = c->num_cus;
+            p.flavour = c->flavour;
+            p.top_pairs = c->top_pairs;
+            p.counts = c->b_planes.as<int32_t>() + (size_t)ph0 * plane_ints;
+            p.count_replicas = R;
+            p.count_stride = c->T;
+            p.error_flag = c->error_flag.as<uint32_t>();
+            p.ox = gx[g];
+            p.oz = gz[g];
+            p.n = (int64_t)kc * n_pad;
+            p.npairs = c->npairs;
+            p.recs = c->b_recs[g].p;
+            p.perm = gperm[g];
+            p.recs_prepared = 1;
+            p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
+            p.plane_batches = (uint32_t)(n_pad / 64);
+            p.plane_n = (uint32_t)n;
+            p.plane_stride = (uint32_t)plane_ints;
+            static const int per_cu[5] = {8, 4, 6, 2, 16};
+            const int gcode = (c->variant / 10) % 10;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->timing) {
+                if (c->ev_used == c->ev_pool.size()) {
+                    hipEvent_t a, b;
+                    HIP_TRY(hipEventCreate(&a));
+                    HIP_TRY(hipEventCreate(&b));
+                    c->ev_pool.emplace_back(a, b);
+                }
+                e0 = c->ev_pool[c->ev_used].first;
+                e1 = c->ev_pool[c->ev_used].second;
+                ++c->ev_used;
+                HIP_TRY(hipEventRecord(e0, ls));
+            }
+            if (!launch_extend6(p, c->variant == 0 ? 1 : c->variant % 10, c->variant == 0 ? 8 : per_cu[gcode < 5 ? gcode : 0], ls)) {
+                c->lane = lane_before;
+                return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: variant %d needs a larger overflow-stack buffer", c->variant);
+            }
+            HIP_TRY(hipGetLastError());
+            if (c->timing) HIP_TRY(hipEventRecord(e1, ls));
         }
-        p.ovf_stack = lane_ovf(c).as<uint32_t>();
-        p.ovf_capacity = lane_ovf(c).bytes / sizeof(uint32_t);
-        p.num_cus = c->num_cus;
-        p.flavour = c->flavour;
-        p.top_pairs = c->top_pairs;
-        p.counts = c->b_planes.as<int32_t>() + (size_t)gfirst[g] * plane_ints;
-        p.count_replicas = R;
-        p.count_stride = c->T;
-        p.error_flag = c->error_flag.as<uint32_t>();
-        p.ox = gx[g];
-        p.oz = gz[g];
-        p.n = (int64_t)gsize[g] * n_pad;
-        p.npairs = c->npairs;
-        p.recs = c->b_recs[g].p;
-        p.perm = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
-        p.perm_root = c->perm_root;
-        p.recs_prepared = 1;
-        p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
-        p.plane_batches = (uint32_t)(n_pad / 64);
-        p.plane_n = (uint32_t)n;
-        p.plane_stride = (uint32_t)plane_ints;
-        static const int per_cu[5] = {8, 4, 6, 2, 16};
-        const int gcode = (c->variant / 10) % 10;
-        if (!launch_extend6(p, c->variant == 0 ? 1 : c->variant % 10, c->variant == 0 ? 8 : per_cu[gcode < 5 ? gcode : 0], ls)) {
-            c->lane = lane_before;
-            return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: variant %d needs a larger overflow-stack buffer", c->variant);
-        }
-        HIP_TRY(hipGetLastError());
     }
     c->lane = 0;
     c->cur_pipelined = false;
@@ -1276,6 +1375,17 @@ int uvrt_advance_seed(uvrt_ctx* c, const float lp[3], float light_length)
     return UVRT_OK;
 }
 
+int uvrt_set_hot_records(uvrt_ctx* c, int32_t mode)
+{
+    if (!c || (mode != 0 && mode != 1)) return fail(UVRT_ERR_INVALID, "uvrt_set_hot_records: mode must be 0 or 1");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
+    c->hot_mode = mode;
+    c->recs_valid = false;
+    for (int l = 0; l < uvrt_ctx::MAXL; ++l) { c->xrecs_valid[l] = false; c->lane_perm[l] = nullptr; }
+    return UVRT_OK;
+}
+
 int uvrt_set_seed_mode(uvrt_ctx* c, int32_t mode)
 {
     if (!c || (mode != 0 && mode != 1)) return fail(UVRT_ERR_INVALID, "uvrt_set_seed_mode: mode must be 0 or 1");
@@ -1359,6 +1469,7 @@ int uvrt_write_rays(uvrt_ctx* c, const void* rays32, int64_t n)
     HIP_TRY(hipMemcpyAsync(c->rays.p, packed.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->recs_valid = false;
+    c->lane_perm[0] = nullptr;
     c->last_n = n;
     c->last_first = 0;
     c->last_sorted = false;
@@ -1386,13 +1497,18 @@ int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
             break;
         case 3: b = &c->dosage; elem = 4; break;
         case 4: b = &c->color; elem = 36; break;
-        default: return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: which must be 0..4");
+        case 5:
+            if (c->b_count <= 0) return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: no traced batch");
+            if (int rc = uvrt_fold_batch(c)) return rc;
+            b = &c->b_folded; elem = 4 * (size_t)c->b_count;
+            break;
+        default: return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: which must be 0..5");
     }
     *ptr = b->p;
     *bytes = (int64_t)((size_t)c->T * elem);
     // see lane_stream(): the next side-lane work (on the maps: the next accumulate / Shade) waits for
     // what the caller enqueues on the main stream up to the next call
-    if (which == 2) c->ext_touch = true; else c->ext_touch_maps = true;
+    if (which == 2 || which == 5) c->ext_touch = true; else c->ext_touch_maps = true;
     return UVRT_OK;
 }
 

@@ -200,7 +200,6 @@ struct ExtendParams {
     void* recs;              // extend v6: [npairs] per-launch pair records + [T] leaf records, 64 B each
     int32_t refill_min;      // extend v6: idle lanes that trigger a refill (16)
     const uint32_t* perm;    // extend v6: record renumbering (nullptr = identity), see prepare_record6
-    uint32_t perm_root;      // perm[0]
     int32_t recs_prepared;   // extend v6: recs[0, npairs) already hold this launch's records (k_generate)
     uint32_t root_ref6;      // root reference in v6's record numbering (set by launch_extend6)
     // batched tracing: `rays` holds nplanes planes of plane_batches * 64 slots each, of which the first
@@ -226,6 +225,10 @@ void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bi
 // extend (uvrt_extend6.hip): code bits 0-1 = leaf period - 1, bit 2 = no LDS top cache; returns false
 // (nothing launched) when the grid would not fit the overflow-stack buffer
 bool launch_extend6(const ExtendParams& p, int code, int grid_per_cu, hipStream_t s);
+// hot-record statistics (uvrt_hotset.hip)
+void launch_visit_stats(const SceneDev& scene, uint32_t* hist, const float lamp[3], float light_length, uint32_t seed_prev,
+                        uint32_t seed_next, int32_t seed_mode, int32_t n, hipStream_t s);
+void launch_select_hot(uint32_t* hist, uint32_t* perm, int32_t npairs, int32_t keep, hipStream_t s);
 void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, int32_t T, hipStream_t s);
 constexpr uint64_t OVF_MAX_ENTRIES = (uint64_t)256 * 16 * 256 * 24;   // largest grid x deepest overflow
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     bool live = false;             // RECORD: holds a ray whose (dist, triID) has not been written yet
     unsigned long long special_mask = 0;   // lanes whose ray needs the EXACT step (wave-uniform value)
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
+    const uint32_t root6 = (p.perm && p.root_ref6 < REF_LEAF_BIT) ? p.perm[p.root_ref6] : p.root_ref6;
     uint32_t plane_off = 0;        // ints from my_counts to the plane of the ray this lane holds
     const float plane_inv = 1.0f / (float)p.plane_batches;
 
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                     set_in_place(L.triID, 0u);
                     if (RECORD) { slot = my; live = true; }
                     set_in_place(L.sp, 0);
-                    set_in_place(L.cur, p.root_ref6);
+                    set_in_place(L.cur, root6);
                     const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
                     const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
                     spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
@@ -454,9 +455,9 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
     const uint64_t waves = (uint64_t)grid * 4;
     p.chunk = (uint32_t)((((uint64_t)p.n + waves - 1) / waves + 63) / 64 * 64);
     if ((uint64_t)grid * 256 * (MAXS6 - PS6) > p.ovf_capacity) return false;
+    // an inner root is translated through the renumbering by the kernel itself (perm lives on the device)
     p.root_ref6 = (p.scene.root_ref >= REF_LEAF_BIT && p.scene.root_ref != REF_DONE)
-                      ? p.scene.root_ref + (uint32_t)p.npairs
-                      : (p.perm && p.scene.root_ref != REF_DONE ? p.perm_root : p.scene.root_ref);
+                      ? p.scene.root_ref + (uint32_t)p.npairs : p.scene.root_ref;
     if (p.perm) p.top_pairs = (uint32_t)p.npairs;   // the hot prefix: as many records as the cache holds
     if (p.npairs > 0 && !p.recs_prepared)
         hipLaunchKernelGGL(k_prepare_launch6, dim3((unsigned)((p.npairs + 255) / 256)), dim3(256), 0, s,

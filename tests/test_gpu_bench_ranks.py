@@ -31,14 +31,20 @@ def bench(args, ranks=1, port=29530):
 def test_two_rank_rehearsal_matches_single_rank():
     common = ["--photons", "300000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
     one = bench(common + ["--waves", "6"])
-    weak = bench(common + ["--waves", "3"], ranks=2, port=29531)                 # 2 ranks x 3 waves = 6 launches
-    strong = bench(common + ["--waves", "6", "--scaling", "strong"], ranks=2, port=29532)
-    assert weak["n_gpus"] == strong["n_gpus"] == 2 and weak["scaling"] == "weak" and strong["scaling"] == "strong"
-    assert weak["multi_gpu_check"]["dose_identical_on_all_ranks"]
-    assert strong["multi_gpu_check"]["dose_identical_on_all_ranks"]
-    assert weak["config"]["rays_per_step"] == strong["config"]["rays_per_step"] == one["config"]["rays_per_step"]
-    assert weak["dose_crc32"] == one["dose_crc32"]
-    assert strong["dose_crc32"] == one["dose_crc32"]
-    for d in (one, weak, strong):
+    two = bench(common + ["--waves", "6"], ranks=2, port=29531)        # strong headline; weak: 2 ranks x 6 waves
+    three = bench(common + ["--waves", "6", "--scaling", "weak"], ranks=3, port=29532)
+    assert one["other_modes"]["batched"]["dose_crc32"] == one["dose_crc32"] and one["config"]["mode"] == "loop"
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and three["scaling"] == "weak"
+    for d in (two, three):
+        assert d["multi_gpu_check"]["dose_identical_on_all_ranks"]
+        # ray-range shards + ONE reduction of the count planes per computation = the single-GPU dose bits
+        assert d["strong"]["dose_crc32"] == one["dose_crc32"]
+        assert d["strong"]["rays_per_step"] == one["config"]["rays_per_step"]
+    assert two["dose_crc32"] == one["dose_crc32"] and two["value"] == two["strong"]["value"]
+    assert three["value"] == three["weak"]["value"] and three["weak"]["rays_per_step"] == 3 * one["config"]["rays_per_step"]
+    # weak at 2 ranks traces 12 launches of the same SEED chain: its dose is the 12-wave single-GPU dose
+    twelve = bench(common + ["--waves", "12"])
+    assert two["weak"]["dose_crc32"] == twelve["dose_crc32"]
+    for d in (one, two, three):
         assert d["roofline"] is None or 0.0 < d["roofline"]["frac"] <= 1.0
         assert d["unit"] == "Mray/s" and d["higher_is_better"] is True
