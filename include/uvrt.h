@@ -243,6 +243,8 @@ int uvrt_extend_time_ms(uvrt_ctx* ctx, double* ms, int64_t* launches);
 int uvrt_set_timing(uvrt_ctx* ctx, int32_t on);
 /* compute units of the context's device (the persistent extend grid is 8 workgroups per CU) */
 int uvrt_device_cus(uvrt_ctx* ctx);
+/* HIP devices visible to the process (0 when there is none) */
+int uvrt_device_count(void);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("uvrt_extend_time_ms", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("uvrt_set_timing", C.c_int, [_vp, _i32]),
     ("uvrt_device_cus", C.c_int, [_vp]),
+    ("uvrt_device_count", C.c_int, []),
 ]
 
 # uvrt_replay_op (include/uvrt.h)

@@ -328,6 +328,11 @@ extern "C" {
 const char* uvrt_last_error(void) { return g_err.c_str(); }
 const char* uvrt_version(void) { return "uvrt-mi355x 0.1 (gfx950)"; }
 int uvrt_device_cus(uvrt_ctx* c) { return c ? c->num_cus : 0; }
+int uvrt_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 int uvrt_create(int device_id, uvrt_ctx** out)
 {

@@ -9,9 +9,15 @@
 //            [--dump dose.f32 | dose.npy]   raw little-endian f32[T] or NumPy .npy (by extension)
 //            [--ply heatmap.ply]            the room with per-triangle heat-map colours
 //                                           (dosageToColor output; what the reference shows in GL)
+//            [--batch K]                    trace K iterations per batch (RayTracer::ComputeIterationsBatched:
+//                                           all launches first, accumulate + Shade replayed; same dose bits)
+//            [--gpus N]                     one process, N contexts: every launch split by global-id range
+//                                           ("pixel tiles"), ONE RCCL all-reduce of the count planes per batch
+//                                           (contexts share a device when the box has fewer than N: no RCCL then)
 #include "raytracer.h"
 #include "../../include/uvrt.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +31,7 @@ int main(int argc, char** argv)
 {
     std::string room, routeDir = "positions/", route = "route", dump, saveRoute, ply;
     long long photons = -1;
-    int iterations = -1, lamps = -1, device = 0;
+    int iterations = -1, lamps = -1, device = 0, gpus = 1, batch = 0;
     bool calibrate = false;
     float calP = 2909.0f, calH = 0.8f, calD = 1.0f;   // userinterface.cpp:107-109 defaults
     ViewMode view = dosage;
@@ -38,6 +44,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--iterations")) { need(1); iterations = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--lamps")) { need(1); lamps = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--device")) { need(1); device = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--gpus")) { need(1); gpus = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--batch")) { need(1); batch = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--dump")) { need(1); dump = argv[++i]; }
         else if (!strcmp(argv[i], "--ply")) { need(1); ply = argv[++i]; }
         else if (!strcmp(argv[i], "--save-route")) { need(1); saveRoute = argv[++i]; }
@@ -68,17 +76,55 @@ int main(int argc, char** argv)
         std::cout << "Calibrated lamp power: " << rayTracer.lightIntensity << std::endl;
     }
 
-    rayTracer.ResetDosageMap();                              // userinterface.cpp:247-251
-    rayTracer.viewMode = view;
+    // --gpus N: further instances of the same RayTracer, one per context, each with its range of every launch
+    std::vector<RayTracer*> group{&rayTracer};
+    std::vector<RayTracer*> extra;
+    if (gpus < 1 || gpus > 64) { fprintf(stderr, "--gpus must be in [1,64]\n"); return 2; }
+    if (gpus > 1) {
+        const int ndev = uvrt_device_count();
+        if (batch <= 0) batch = 1;
+        for (int r = 1; r < gpus; ++r) {
+            RayTracer* rt = new RayTracer();
+            rt->deviceId = ndev >= gpus ? device + r : device;
+            rt->routeDir = routeDir;
+            rt->autoSaveRoute = false;
+            strncpy(rt->defaultRouteFile, route.c_str(), 31);
+            rt->Init(&mesh);
+            rt->lightPositions = rayTracer.lightPositions;
+            rt->photonCount = rayTracer.photonCount;
+            rt->maxIterations = rayTracer.maxIterations;
+            rt->lightIntensity = rayTracer.lightIntensity;
+            rt->UpdatePhotonsPerLight();
+            extra.push_back(rt);
+            group.push_back(rt);
+        }
+        if (ndev >= gpus) {
+            std::vector<uvrt_ctx*> ctxs;
+            for (RayTracer* rt : group) ctxs.push_back(rt->ctx);
+            if (uvrt_comm_init_all(ctxs.data(), gpus) != UVRT_OK) { fprintf(stderr, "comm_init_all: %s\n", uvrt_last_error()); return 1; }
+            std::cout << "Sharding every launch over " << gpus << " GPUs, one RCCL all-reduce of the count planes per batch" << std::endl;
+        } else {
+            std::cout << "Sharding every launch over " << gpus << " contexts on " << ndev << " GPU(s) (rehearsal: no RCCL)" << std::endl;
+        }
+    }
+    for (size_t r = 0; r < group.size(); ++r) {
+        group[r]->ResetDosageMap();                          // userinterface.cpp:247-251
+        group[r]->viewMode = view;
+        if (gpus > 1) group[r]->SetRayRange((int)r, gpus);
+    }
     while (!rayTracer.finishedComputation) {                 // myapp.cpp:156-175
         rayTracer.finishedComputation = rayTracer.currIterations >= rayTracer.maxIterations;
         if (rayTracer.finishedComputation) break;
-        rayTracer.ComputeDosageMap();
-        rayTracer.Shade();
+        if (batch > 0) {
+            RayTracer::ComputeIterationsBatched(group, std::min(batch, rayTracer.maxIterations - rayTracer.currIterations));
+        } else {
+            rayTracer.ComputeDosageMap();
+            rayTracer.Shade();
+            rayTracer.currIterations++;
+        }
         if (rayTracer.viewMode == texture) rayTracer.viewMode = dosage;
-        rayTracer.currIterations++;
         rayTracer.progress = 100.0f * static_cast<float>(rayTracer.currIterations) / static_cast<float>(rayTracer.maxIterations);
-        rayTracer.Sync();
+        for (RayTracer* rt : group) rt->Sync();
         float time = rayTracer.timerClock.elapsed();
         rayTracer.compTime += time;
         std::cout << "Progress: " << rayTracer.progress << "% photon count: " << rayTracer.photonMapSize
@@ -136,6 +182,13 @@ int main(int argc, char** argv)
             f.write((const char*)&three, 1);
             f.write((const char*)idx, 12);
         }
+    }
+    for (RayTracer* rt : extra) {
+        // every instance holds the same maps after the reduction: check it, then drop the helpers
+        std::vector<float> other(mesh.triangleCount);
+        rt->ReadDosage(other.data(), 0, mesh.triangleCount);
+        if (memcmp(other.data(), dose.data(), dose.size() * 4) != 0) { fprintf(stderr, "rank doses differ\n"); return 1; }
+        delete rt;
     }
     if (!saveRoute.empty()) {
         char name[32];

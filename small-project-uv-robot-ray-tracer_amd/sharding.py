@@ -2,7 +2,10 @@
 on the GPU box, "gloo" in CPU tests).  torch is plumbing here: device selection, the process
 group and the collective; the maps it reduces live in the uvrt context.
 
-The path shards by LAUNCH.  A computation is a fixed global sequence of lamp launches
+Two ways to shard.  By RAY RANGE (BASELINE configs[3], the default of bench.py at N > 1): every
+rank traces its global-id range of EVERY launch into private int32 count planes, one SUM all-reduce of the
+planes per batch (native: uvrt_reduce_batch over RCCL), then every rank replays accumulate + Shade -- see
+ray_range / reduce_planes below and include/uvrt.h "batched tracing".  By LAUNCH (configs[4]):  A computation is a fixed global sequence of lamp launches
 (iteration-major, lamp-minor: raytracer.cpp:66-72 inside myapp.cpp:156-163); launch k is traced
 by rank k % world, every rank advances generate.cl's SEED chain over all launches
 (RayTracer::shardRank/shardWorld), and the only exchange is one reduction at the end:
@@ -46,6 +49,24 @@ def seed_chain(lamp_world_positions, light_length, iterations, seed0=0):
         seeds.append(s)
         s = capi.seed_next(lamp_world_positions[li], light_length, s)
     return seeds, s
+
+
+def ray_range(rank, world, n):
+    """(first, count): the contiguous share of the global ids [0, n) of every launch that `rank` traces in a
+    ray-range-sharded job (RayTracer::SetRayRange; the union over the ranks is the whole launch)."""
+    share = (n + world - 1) // world
+    first = min(rank * share, n)
+    return first, min(share, n - first)
+
+
+def reduce_planes(planes, group=None):
+    """In-place int32 SUM all-reduce of the count planes [launches][T] of a batch: the ONE collective of a
+    ray-range-sharded computation (the native path is uvrt_reduce_batch; this is the torch.distributed form
+    for rehearsals on gloo)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(planes, op=dist.ReduceOp.SUM, group=group)
 
 
 def reduce_maps(sum_map, max_map, group=None):

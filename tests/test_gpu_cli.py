@@ -40,3 +40,21 @@ def test_cli_tick_loop_and_exports(tmp_path, orc, oscene, oroute):
     assert np.array_equal(v["p"].reshape(T, 9), oscene.tris[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]])
     col = orc.dosage_to_color(ref, oroute["minDosage"], False)
     assert np.array_equal(v["c"].reshape(T, 9), np.floor(np.clip(col, 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))
+
+
+def test_cli_sharded_and_batched_runs_give_the_same_dose(tmp_path):
+    """uvrt_cli --gpus 3 (one process, three contexts on the one device, every launch split by global-id
+    range, one sum of the count planes per batch, native host loop in C++) and --batch 2 against the plain
+    per-iteration run: identical dose files."""
+    base = [CLI, "--room", GLB, "--route-dir", GOLDEN, "--route", "lange_route", "--lamps", "3", "--photons", "150000",
+            "--iterations", "4"]
+    outs = {}
+    for tag, extra in (("plain", []), ("batch", ["--batch", "2"]), ("gpus", ["--gpus", "3"]), ("gpus_batch", ["--gpus", "2", "--batch", "4"])):
+        f = tmp_path / (tag + ".f32")
+        out = subprocess.run(base + extra + ["--dump", str(f)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr + out.stdout
+        outs[tag] = (np.fromfile(f, dtype="<u4"), out.stdout)
+    for tag in ("batch", "gpus", "gpus_batch"):
+        assert np.array_equal(outs[tag][0], outs["plain"][0]), tag
+    assert outs["plain"][1].count("Progress: ") == 4 and outs["batch"][1].count("Progress: ") == 2
+    assert "Sharding every launch over 3 contexts" in outs["gpus"][1] and outs["plain"][0].any()
