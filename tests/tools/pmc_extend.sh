@@ -22,10 +22,17 @@ PASSES=(
  "WRITE_SIZE"
  "TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_ATOMIC_sum"
 )
+# PMC_ARGS: profile `python3 bench.py $PMC_ARGS` instead of the quick probe (e.g. "--scene soup:1000000 --steps 3
+# --warmup 1 --no-cpu-baseline --no-pipeline"); PMC_PASSES: only the passes whose counters match this regex
 i=0
 fail=0
 for P in "${PASSES[@]}"; do
-  N=${N:-2073600} VARIANTS=$V SORTS=$S FLAVOUR=$F CHECK=0 timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $REPO/$OUT/p$i -- python3 $REPO/tests/tools/quick_extend_bench.py > $REPO/$OUT/p$i.log 2>&1 || { echo "pass $i ($P) FAILED"; fail=1; }
+  if [ -n "${PMC_PASSES:-}" ] && ! echo "$P" | grep -Eq "$PMC_PASSES"; then i=$((i+1)); continue; fi
+  if [ -n "${PMC_ARGS:-}" ]; then
+    (cd $REPO && timeout -k 10 400 rocprofv3 --pmc $P --output-format csv -d $REPO/$OUT/p$i -- python3 $REPO/bench.py $PMC_ARGS > $REPO/$OUT/p$i.log 2>&1) || { echo "pass $i ($P) FAILED"; fail=1; }
+  else
+    N=${N:-2073600} VARIANTS=$V SORTS=$S FLAVOUR=$F CHECK=0 timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $REPO/$OUT/p$i -- python3 $REPO/tests/tools/quick_extend_bench.py > $REPO/$OUT/p$i.log 2>&1 || { echo "pass $i ($P) FAILED"; fail=1; }
+  fi
   i=$((i+1))
 done
 python3 - <<PY
