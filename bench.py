@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: launches do not overlap")
     ap.add_argument("--sort-bits", type=int, default=None)
     ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--wide", action="store_true",
+                    help="opt-in 4-wide BVH walk (include/uvrt.h uvrt_set_wide_bvh): not the reference's visit order; the "
+                         "dose check against the oracle still applies (it fails on a scene with order-dependent rays)")
     ap.add_argument("--flavour", type=int, default=0, choices=[0, 1],
                     help="arithmetic flavour of IntersectTri (include/uvrt.h uvrt_set_flavour): 0 = canonical strict "
                          "(SURVEY 8c), 1 = the fused cross/dot ROCm's OpenCL gives the reference's extend.cl on gfx950")
@@ -231,6 +234,8 @@ def main():
     if args.no_pipeline:
         rt.ctx.set_pipeline(False)
     rt.ctx.set_flavour(args.flavour)
+    if args.wide:
+        rt.ctx.set_wide_bvh(True)
     n_launch = rt.photonsPerLight
     lamp = rt.lamps()[0]
     lp = (lamp[0], float(np.float32(np.float32(rt.mesh.floorHeight) + np.float32(rt.lightHeight))), lamp[1])
@@ -428,7 +433,7 @@ def main():
             model_path = os.path.join(ROOT, "profiles", "extend_issue_model_%s.json" % args.mode)
             if not os.path.exists(model_path):
                 model_path = os.path.join(ROOT, "profiles", "extend_issue_model.json")
-            if os.path.exists(model_path) and args.scene is None:
+            if os.path.exists(model_path) and args.scene is None and not args.wide:
                 # The binding resource, priced with the per-ray instruction / lookup / byte counts of the kernel
                 # (rocprofv3 PMC passes, deterministic per launch; tests/tools/issue_model.py) and the issue rates
                 # calibrated on this GPU type (tests/tools/valu_calib.hip, profiles/r02_valu_calibration.txt);
@@ -506,7 +511,8 @@ def main():
                                    % (scene_label, n_launch, args.waves, " per GPU" if (world > 1 and args.scaling == "weak") else "",
                                       step_text),
                        "triangles": rt.mesh.triangleCount, "rays_per_step": rays_per_step, "mode": args.mode,
-                       "launch_pipelining": bool(not args.no_pipeline), "flavour": args.flavour, "parallelism": par},
+                       "launch_pipelining": bool(not args.no_pipeline), "flavour": args.flavour, "wide_bvh": bool(args.wide),
+                       "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,
             "dose_crc32": crc_timed, "dose_crc32_expected": expected, "dose_crc32_after_all_passes": crc(dose_after),
             "value_is": "steady-state throughput of back-to-back computations (one device sync after the last step)",

@@ -186,6 +186,13 @@ int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
  * run live on the same GPU, bit for bit.  Everything else (slab test, traversal, deposit) is
  * common to both flavours. */
 int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
+/* OPT-IN 4-wide traversal: uvrt_extend walks a one-level collapse of the caller's BVH
+ * (a node holds its grandchildren's boxes) -- about half the loop trips per ray, the same box and triangle
+ * arithmetic, but NOT the reference's visit order: `dist` and `triID` equal the default kernel's except on
+ * rays where two accepted hits tie exactly in t or a box is culled by an almost equally distant earlier hit
+ * (extend.cl:25,66-76 make those order-dependent; none in 25 M rays on the test room).  Off by default: the
+ * default walk is bit-exact unconditionally.  uvrt_trace_batch always uses the default walk. */
+int uvrt_set_wide_bvh(uvrt_ctx* ctx, int32_t on);
 /* Which node-pair records the traversal serves from LDS: 1 (default) = the 127 records the lamp's photons
  * visit most, found on the device from a sample of the launch's own rays the first time a lamp position is
  * seen (62-70 % of all inner-node visits on the test room); 0 = the first 127 in breadth-first order

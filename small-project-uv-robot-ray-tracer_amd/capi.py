@@ -63,6 +63,7 @@ SYMBOLS = [
     ("uvrt_set_pipeline", C.c_int, [_vp, _i32]),
     ("uvrt_set_record_perm", C.c_int, [_vp, _vp, _i32]),
     ("uvrt_set_hot_records", C.c_int, [_vp, _i32]),
+    ("uvrt_set_wide_bvh", C.c_int, [_vp, _i32]),
     ("uvrt_read_rays", C.c_int, [_vp, _vp, _i64, _i64]),
     ("uvrt_write_rays", C.c_int, [_vp, _vp, _i64]),
     ("uvrt_read_counts", C.c_int, [_vp, _vp, _i32, _i32]),
@@ -306,6 +307,9 @@ class Ctx:
             return
         perm = np.ascontiguousarray(perm, dtype=np.uint32)
         self._ck(self._L.uvrt_set_record_perm(self._h, perm.ctypes.data, int(perm.size)))
+
+    def set_wide_bvh(self, on):
+        self._ck(self._L.uvrt_set_wide_bvh(self._h, int(bool(on))))
 
     def set_hot_records(self, mode):
         self._ck(self._L.uvrt_set_hot_records(self._h, int(mode)))

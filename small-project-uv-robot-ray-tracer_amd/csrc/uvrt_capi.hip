@@ -122,6 +122,15 @@ struct uvrt_ctx {
     bool xrecs_valid[MAXL] = {};
     float xrecs_ox[MAXL] = {}, xrecs_oz[MAXL] = {};
 
+    // Opt-in 4-wide collapse of the BVH (uvrt_set_wide_bvh, uvrt_extend4.hip)
+    bool wide = false;
+    DevBuf quads;                         // [nquads] QuadRec, scene form
+    DevBuf recs4[MAXL];                   // per lane: [2 * nquads + T + 1] 64-byte units, per-launch form + leaf records
+    int32_t nquads = 0;
+    uint32_t top_quads = 0;
+    bool recs4_valid[MAXL] = {};          // recs4[l] hold the per-launch records of lamp column (recs4_ox, recs4_oz)
+    float recs4_ox[MAXL] = {}, recs4_oz[MAXL] = {};
+
     // Hot-record renumbering per lamp position (uvrt_hotset.hip): the records a lamp's photons visit most are
     // the ones the traversal serves from LDS.  Built on the device the first time a lamp is seen.
     struct HotEntry { float lamp[3]; DevBuf perm, hist; uint64_t stamp; hipEvent_t ready; };
@@ -390,6 +399,8 @@ void uvrt_destroy(uvrt_ctx* c)
     if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
     if (c->ev_mapfence) (void)hipEventDestroy(c->ev_mapfence);
     if (c->comm) uvrt_comm_destroy(c);
+    c->quads.release();
+    for (DevBuf& b : c->recs4) b.release();
     for (DevBuf& b : c->b_recs) b.release();
     for (auto& h : c->hot) { h.perm.release(); h.hist.release(); (void)hipEventDestroy(h.ready); }
     for (DevBuf* b : {&c->b_rays, &c->b_planes, &c->b_folded}) b->release();
@@ -491,6 +502,65 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         if (depth[qi] < 7 && top_pairs < 127) top_pairs = (uint32_t)qi + 1;   // level order: a prefix
     }
     if (err) return fail(UVRT_ERR_BVH, "uvrt_set_scene: malformed BVH (code %d)", err);
+    // The 4-wide collapse (one level): a node takes the children of its inner children.  Numbered breadth-first
+    // like the pairs; a child reference is a 64-byte unit index (2 x node index) or the BVH2 leaf reference.
+    std::vector<QuadRec> quads;
+    uint32_t top_quads = 0;
+    if (!pairs.empty()) {
+        std::vector<int32_t> qpair{0};        // pair index (of the BVH2 inner node) of every 4-wide node
+        std::vector<int32_t> qdepth{0};
+        const float far_box = 1e30f;          // an empty slot: a box no ray reaches (entry distance >= 1e30)
+        for (size_t qi = 0; qi < qpair.size(); ++qi) {
+            struct Child { float mn[3], mx[3]; uint32_t ref; };
+            Child ch[4];
+            int nch = 0;
+            auto add = [&](const float4& mn, const float4& mx, uint32_t ref) {
+                Child& c4 = ch[nch++];
+                c4.mn[0] = mn.x; c4.mn[1] = mn.y; c4.mn[2] = mn.z;
+                c4.mx[0] = mx.x; c4.mx[1] = mx.y; c4.mx[2] = mx.z;
+                c4.ref = ref;
+            };
+            auto children_of = [&](const PairRec& pr, float4 mn[2], float4 mx[2], uint32_t ref[2]) {
+                mn[0] = pr.c0min_ref0; mx[0] = pr.c0max_ref1; mn[1] = pr.c1min; mx[1] = pr.c1max;
+                memcpy(&ref[0], &pr.c0min_ref0.w, 4);
+                memcpy(&ref[1], &pr.c0max_ref1.w, 4);
+            };
+            float4 mn[2], mx[2];
+            uint32_t ref[2];
+            children_of(pairs[qpair[qi]], mn, mx, ref);
+            for (int k = 0; k < 2; ++k) {
+                if (ref[k] >= REF_LEAF_BIT) { add(mn[k], mx[k], ref[k]); continue; }
+                float4 gmn[2], gmx[2];
+                uint32_t gref[2];
+                children_of(pairs[ref[k]], gmn, gmx, gref);
+                for (int j = 0; j < 2; ++j) add(gmn[j], gmx[j], gref[j]);
+            }
+            QuadRec q;
+            memset(&q, 0, sizeof q);
+            float y[4][2];
+            for (int k = 0; k < 4; ++k) {
+                if (k < nch) {
+                    uint32_t r = ch[k].ref;
+                    if (r < REF_LEAF_BIT) {           // inner: it becomes a 4-wide node of its own
+                        qpair.push_back((int32_t)r);
+                        qdepth.push_back(qdepth[qi] + 1);
+                        r = 2u * (uint32_t)(qpair.size() - 1);
+                    }
+                    q.xz[k] = make_float4(ch[k].mn[0], ch[k].mx[0], ch[k].mn[2], ch[k].mx[2]);
+                    y[k][0] = ch[k].mn[1]; y[k][1] = ch[k].mx[1];
+                    q.ref[k] = r;
+                } else {
+                    q.xz[k] = make_float4(far_box, far_box, far_box, far_box);
+                    y[k][0] = y[k][1] = far_box;
+                    q.ref[k] = REF_DONE;
+                }
+            }
+            q.y01 = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]);
+            q.y23 = make_float4(y[2][0], y[2][1], y[3][0], y[3][1]);
+            quads.push_back(q);
+            if (qdepth[qi] < 4 && top_quads < 64) top_quads = (uint32_t)qi + 1;     // levels 0-3: up to 85 nodes, 64 cached
+        }
+    }
     // a child reference is a record index with 32-bit byte offsets: inner-node records + leaf records < 2^26
     if (pairs.size() + (size_t)T >= ((size_t)1 << 26))
         return fail(UVRT_ERR_INVALID, "uvrt_set_scene: %zu inner nodes + %d triangles exceed 2^26 records", pairs.size(), T);
@@ -526,6 +596,10 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     }
     if (!pairs.empty())
         HIP_TRY(hipMemcpyAsync(c->pairs.p, pairs.data(), pairs.size() * sizeof(PairRec), hipMemcpyHostToDevice, c->stream));
+    if ((rc = c->quads.ensure(std::max<size_t>(quads.size(), 1) * sizeof(QuadRec), false, c->stream))) return rc;
+    if (!quads.empty())
+        HIP_TRY(hipMemcpyAsync(c->quads.p, quads.data(), quads.size() * sizeof(QuadRec), hipMemcpyHostToDevice, c->stream));
+    for (DevBuf& b : c->recs4) b.release();              // sized per scene; rebuilt on demand (uvrt_set_wide_bvh)
     HIP_TRY(hipMemcpyAsync(c->leaf_count.p, leaf_count.data(), (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
     // staging copies of the reference-layout arrays for the device-side preparation kernel
     DevBuf d_tris, d_idx;
@@ -550,6 +624,9 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->root_ref = root_ref;
     c->top_pairs = top_pairs;
     c->npairs = (int32_t)pairs.size();
+    c->nquads = (int32_t)quads.size();
+    c->top_quads = top_quads;
+    for (int l = 0; l < uvrt_ctx::MAXL; ++l) c->recs4_valid[l] = false;
     c->recs_valid = false;
     for (int l = 0; l < uvrt_ctx::MAXL; ++l) c->xrecs_valid[l] = false;
     c->have_perm = false;
@@ -793,6 +870,32 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         e1 = c->ev_pool[c->ev_used].second;
         ++c->ev_used;
         HIP_TRY(hipEventRecord(e0, ls));
+    }
+    if (c->wide && c->nquads > 0) {
+        // the opt-in 4-wide walk: its per-launch records are (re)made here when the lane's are for another lamp
+        DevBuf& r4 = c->recs4[c->lane];
+        if (!r4.p) {
+            if (int rc = r4.ensure(((size_t)2 * c->nquads + (size_t)c->T + 1) * 64, true, ls)) return rc;
+            launch_prepare_leaves6(c->ltris.as<LeafTri>(), r4.p, 2 * c->nquads, c->T, ls);
+            c->recs4_valid[c->lane] = false;
+        }
+        if (!c->recs4_valid[c->lane] || memcmp(&c->recs4_ox[c->lane], &c->ox, 4) != 0 || memcmp(&c->recs4_oz[c->lane], &c->oz, 4) != 0) {
+            launch_prepare_launch4(c->quads.as<QuadRec>(), r4.p, c->ox, c->oz, c->nquads, ls);
+            c->recs4_valid[c->lane] = true;
+            c->recs4_ox[c->lane] = c->ox;
+            c->recs4_oz[c->lane] = c->oz;
+        }
+        p.recs4 = r4.p;
+        p.nquads = c->nquads;
+        p.top_quads = c->top_quads;
+        p.refill_min = 8;
+        if (c->variant >= 500 && c->variant < 600) p.force_exact = 1;
+        if (!launch_extend4(p, 7, ls)) return fail(UVRT_ERR_INVALID, "uvrt_extend: overflow-stack buffer too small for the 4-wide kernel");
+        HIP_TRY(hipGetLastError());
+        if (c->timing) HIP_TRY(hipEventRecord(e1, ls));
+        c->counts_dirty[c->lane] = true;
+        c->last_extended = c->record_hits;
+        return UVRT_OK;
     }
     if (c->variant >= 500 && c->variant < 600) p.force_exact = 1;
     p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
@@ -1377,6 +1480,15 @@ int uvrt_advance_seed(uvrt_ctx* c, const float lp[3], float light_length)
 {
     if (!c || !lp) return fail(UVRT_ERR_INVALID, "uvrt_advance_seed: null argument");
     c->seed = uvrt_seed_next_mode(lp, light_length, c->seed, c->seed_mode);
+    return UVRT_OK;
+}
+
+int uvrt_set_wide_bvh(uvrt_ctx* c, int32_t on)
+{
+    if (!c) return fail(UVRT_ERR_INVALID, "null context");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
+    c->wide = on != 0;
     return UVRT_OK;
 }
 

@@ -35,6 +35,16 @@ struct alignas(16) LeafTri {   // 48 B
     float4 e2;                 // v2 - v0
 };
 
+// 4-wide node of the opt-in collapsed tree (uvrt_extend4.hip): the boxes of up to four children -- the
+// grandchildren of a node of the reference's BVH2 where its children are inner nodes -- and a reference to
+// each.  128 bytes = two 64-byte record units; an empty slot holds a box no ray can hit and REF_DONE.
+struct alignas(16) QuadRec {
+    float4 xz[4];              // child k: min.x, max.x, min.z, max.z  (per launch: minus the lamp's x / z)
+    float4 y01, y23;           // c0 min.y, c0 max.y, c1 min.y, c1 max.y ; likewise c2, c3
+    uint32_t ref[4];           // inner: unit index (2 x node index); leaf: as in the BVH2 form, re-based per launch
+    uint32_t pad[4];
+};
+
 struct SceneDev {
     const PairRec* pairs;
     const LeafTri* ltris;
@@ -208,6 +218,11 @@ struct ExtendParams {
     uint32_t plane_batches;
     uint32_t plane_n;
     uint32_t plane_stride;
+    // the 4-wide form (uvrt_extend4.hip): per-launch records [2 * nquads units of 64 B] + leaf records
+    const void* recs4;
+    int32_t nquads;
+    uint32_t top_quads;      // nodes [0, top_quads) are served from LDS
+    uint32_t root_ref4;      // REF_DONE / a leaf reference (re-based) / 0
 };
 
 // launch wrappers (uvrt_kernels.hip)
@@ -225,6 +240,9 @@ void launch_scatter(const float4* rays, const uint2* keyrank, const uint32_t* bi
 // extend (uvrt_extend6.hip): code bits 0-1 = leaf period - 1, bit 2 = no LDS top cache; returns false
 // (nothing launched) when the grid would not fit the overflow-stack buffer
 bool launch_extend6(const ExtendParams& p, int code, int grid_per_cu, hipStream_t s);
+// the opt-in 4-wide traversal (uvrt_extend4.hip)
+bool launch_extend4(const ExtendParams& p, int grid_per_cu, hipStream_t s);
+void launch_prepare_launch4(const QuadRec* quads, void* recs4, float ox, float oz, int32_t nquads, hipStream_t s);
 // hot-record statistics (uvrt_hotset.hip)
 void launch_visit_stats(const SceneDev& scene, uint32_t* hist, const float lamp[3], float light_length, uint32_t seed_prev,
                         uint32_t seed_next, int32_t seed_mode, int32_t n, hipStream_t s);

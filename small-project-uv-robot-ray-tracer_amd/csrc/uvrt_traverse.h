@@ -1,0 +1,160 @@
+// uvrt_traverse.h -- device helpers shared by the traversal kernels (uvrt_extend6.hip: the reference's
+// BVH2 order; uvrt_extend4.hip: the opt-in 4-wide collapse): exact slab distances, box and triangle tests,
+// the per-lane ray state, the stack-overflow pointer.  See uvrt_extend6.hip's header for the arithmetic.
+#pragma once
+#include "uvrt_device.h"
+
+namespace uvrt {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int MAXS6 = 32;                 // extend.cl:43
+constexpr int PS6 = 8;                    // LDS stack entries per lane
+constexpr uint32_t TOP6_MAX = 127;        // records cached in LDS
+constexpr uint32_t TOP6_STRIDE = 80;      // bytes per cached record (64 + 16 padding): 10 KB
+
+// The six slab distances of one child box (extend.cl:31-37), correctly rounded:
+//   t = a / d  as  q0 = a * y;  r = fma(-d, q0, a);  q = fma(r, y, q0),   y = RN32(1/d)
+// for the three (min, max) numerator pairs x, z (already a = b - o) and y (raw bounds: the ray's
+// origin y is subtracted first).  px/py/pz = {d, y} per axis, po = {origin y, .}; every step is one
+// packed instruction with the broadcast of d, y or o done by op_sel.  One asm block so that the
+// three chains are interleaved by hand and need exactly three temporary register pairs.
+__device__ __forceinline__ void slabs6(v2f& x, v2f& y, v2f& z, v2f px, v2f py, v2f pz, v2f po)
+{
+    v2f tx, ty, tz;
+    asm("v_pk_add_f32 %[y], %[y], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[tx], %[x], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[tz], %[z], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[ty], %[y], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_fma_f32 %[x], %[px], %[tx], %[x] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[z], %[pz], %[tz], %[z] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[y], %[py], %[ty], %[y] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[x], %[x], %[px], %[tx] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[z], %[z], %[pz], %[tz] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[y], %[y], %[py], %[ty] op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz)
+        : [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [po] "v"(po));
+}
+
+// extend.cl:29-38 from the three (t at min, t at max) pairs: entry distance and hit flag.  No operand
+// is NaN on this path, so v_min/v_max equal OpenCL's y<x?y:x / x<y?y:x.
+__device__ __forceinline__ bool box_fast(v2f tx, v2f ty, v2f tz, float dist, float& tmin)
+{
+    float nx, fx, ny, fy, nz, fz, tmax;
+    asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(tx.x), "v"(tx.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(tx.x), "v"(tx.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ty.x), "v"(ty.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ty.x), "v"(ty.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(nx), "v"(ny), "v"(nz));   // max(max(nx, ny), nz)
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(fx), "v"(fy), "v"(fz));   // min(min(fx, fy), fz)
+    return (tmax >= tmin) & (tmin < dist) & (tmax > 0);
+}
+
+// the reference's own form: IEEE divisions, OpenCL min/max as selects (NaN operands: 0/0)
+__device__ __forceinline__ bool box_exact(float ax1, float ax2, float ay1, float ay2, float az1, float az2,
+                                          float dx, float dy, float dz, float dist, float& tmin_out)
+{
+    const float tx1 = ax1 / dx, tx2 = ax2 / dx;
+    float tmin = tx2 < tx1 ? tx2 : tx1, tmax = tx1 < tx2 ? tx2 : tx1;
+    const float ty1 = ay1 / dy, ty2 = ay2 / dy;
+    const float mny = ty2 < ty1 ? ty2 : ty1, mxy = ty1 < ty2 ? ty2 : ty1;
+    tmin = tmin < mny ? mny : tmin;
+    tmax = mxy < tmax ? mxy : tmax;
+    const float tz1 = az1 / dz, tz2 = az2 / dz;
+    const float mnz = tz2 < tz1 ? tz2 : tz1, mxz = tz1 < tz2 ? tz2 : tz1;
+    tmin = tmin < mnz ? mnz : tmin;
+    tmax = mxz < tmax ? mxz : tmax;
+    tmin_out = tmin;
+    return tmax >= tmin && tmin < dist && tmax > 0;
+}
+
+// RN32(1 / a) for 2^-64 <= |a| < 2^64 (file header)
+__device__ __forceinline__ float rcp_exact(float a)
+{
+    float y0;
+    asm("v_rcp_f32 %0, %1" : "=v"(y0) : "v"(a));
+    const float e = __builtin_fmaf(-a, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+
+// extend.cl:6-27 on a leaf record (v0, e1 = v1 - v0, e2 = v2 - v0, id in v0.w).
+// OCL = the "ocl-amd" flavour (include/uvrt.h uvrt_set_flavour): cross() and dot() in the fused forms
+// ROCm's OpenCL device library gives the reference's extend.cl on gfx950 (read off the disassembly of
+// that kernel as built for gfx950): cross(a, b).x = fma(a.y, b.z, -(a.z * b.y)), dot(a, b) = fma(a.z, b.z,
+// fma(a.y, b.y, a.x * b.x)); everything else as extend.cl writes it.
+template <bool OCL>
+__device__ __forceinline__ float cross6(float ay, float bz, float az, float by)
+{
+    return OCL ? __builtin_fmaf(ay, bz, -(az * by)) : ay * bz - az * by;
+}
+template <bool OCL>
+__device__ __forceinline__ float dot6(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return OCL ? __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx)) : ax * bx + ay * by + az * bz;
+}
+template <bool OCL>
+__device__ __forceinline__ void tri6(float ox, float oy, float oz, float dx, float dy, float dz, float& dist,
+                                     uint32_t& triID, const float4 v0, const float4 e1, const float4 e2,
+                                     bool exact)
+{
+    const float hx = cross6<OCL>(dy, e2.z, dz, e2.y);
+    const float hy = cross6<OCL>(dz, e2.x, dx, e2.z);
+    const float hz = cross6<OCL>(dx, e2.y, dy, e2.x);
+    const float a = dot6<OCL>(e1.x, e1.y, e1.z, hx, hy, hz);
+    if (fabsf(a) < 0.00001f) return;
+    float f;
+    if (exact) f = 1.0f / a;         // wave-uniform
+    else f = rcp_exact(a);
+    const float sx = ox - v0.x, sy = oy - v0.y, sz = oz - v0.z;
+    const float u = f * dot6<OCL>(sx, sy, sz, hx, hy, hz);
+    if ((u < 0) | (u > 1)) return;
+    const float qx = cross6<OCL>(sy, e1.z, sz, e1.y);
+    const float qy = cross6<OCL>(sz, e1.x, sx, e1.z);
+    const float qz = cross6<OCL>(sx, e1.y, sy, e1.x);
+    const float v = f * dot6<OCL>(dx, dy, dz, qx, qy, qz);
+    if ((v < 0) | (u + v > 1)) return;
+    const float tt = f * dot6<OCL>(e2.x, e2.y, e2.z, qx, qy, qz);
+    if (tt > 0.0001f && tt < dist) {
+        dist = tt;
+        triID = __float_as_uint(v0.w);
+    }
+}
+
+// In-place update of a loop-carried value inside a divergent branch: the write happens under the
+// branch's exec mask into the SAME register, so hipcc has no second copy of the value to merge (it
+// otherwise keeps a loop-carried and an in-body copy of the ray constants and moves one into the
+// other on every trip).
+__device__ __forceinline__ void set_in_place(float& dst, float v) { asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(v)); }
+__device__ __forceinline__ void set_in_place(uint32_t& dst, uint32_t v) { asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(v)); }
+__device__ __forceinline__ void set_in_place(int& dst, int v) { asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(v)); }
+__device__ __forceinline__ void set_in_place(v2f& dst, float lo, float hi)
+{
+    const v2f v = {lo, hi};
+    asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "+v"(dst) : "v"(v));
+}
+
+struct Lane6 {
+    v2f px, py, pz;         // {d, RN32(1/d)} per axis
+    v2f po;                 // {origin y, dist}
+    uint32_t triID;
+    uint32_t cur;           // record reference: index | leaf bit + count code, REF_DONE = no ray
+    int sp;
+};
+
+// One traversal step of one lane (extend.cl:44-80): an inner node (both children tested, ordered,
+// descend / push / pop) or -- on a leaf trip -- a leaf (its triangles, pop).
+// Stack entries 8..31 of this thread live in global memory (0.02 % of pushes on the test room).  The
+// pointer is rebuilt from scratch where it is needed -- opaque to the compiler, which would otherwise
+// keep it in two VGPRs (or a scratch slot) across the whole loop.
+__device__ __forceinline__ uint32_t* ovf_ptr(const ExtendParams& p)
+{
+    uint32_t lane, wv;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(wv) : "s"(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)));
+    return p.ovf_stack + ((size_t)blockIdx.x * 256 + wv * 64 + lane) * (MAXS6 - PS6);
+}
+
+}  // namespace uvrt
