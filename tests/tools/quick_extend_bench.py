@@ -19,6 +19,10 @@ c = pkg.capi.Ctx(0)
 c.set_scene(s.tris, s.nodes, s.triIdx)
 c.resize_rays(n)
 c.set_flavour(int(os.environ.get("FLAVOUR", "0")))
+if os.environ.get("WIDE", "0") == "1":
+    c.set_wide_bvh(True)
+if os.environ.get("HOT", "1") == "0":
+    c.set_hot_records(0)
 if os.environ.get("PIPELINE", "1") == "0":
     c.set_pipeline(False)
 ref = None
