@@ -580,8 +580,11 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     if ((rc = c->area.ensure((size_t)T * 4, false, c->stream))) return rc;
     if (resized || !c->photon_map.p) {
         // raytracer.cpp:32-37 (the reference leaves them uninitialised until reset; zero here)
+        // The colour buffer stands for the GL vertex buffer of the caller's mesh (raytracer.cpp:37): a scene swap
+        // does not touch it.  It only grows, so CalibratePower's detour over a 2-triangle scene
+        // (raytracer.cpp:166-224, ClearBuffers(false)) leaves the room's colours as they were.
         for (DevBuf* b : {&c->photon_map, &c->max_map, &c->counts, &c->xcounts[1], &c->xcounts[2], &c->xcounts[3],
-                          &c->dosage, &c->color}) b->release();
+                          &c->dosage}) b->release();
         if ((rc = c->photon_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         if ((rc = c->max_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         // up to 64 deposit replicas, at most 64 MiB in total

@@ -207,3 +207,25 @@ def test_rccl_all_reduce_of_the_planes_single_rank_communicator(pkg, orc, oscene
     finally:
         a.close()
         b.close()
+
+
+def test_baseline_config_1_shape_host_loop(pkg, orc, oscene, oroute):
+    """BASELINE configs[1]: "1280x720 4-bounce on one MI355X" = 921 600 photons x 4 waves from lamp 0 through the
+    reference's host loop (launch pipelining on, hot-record cache on: the defaults), dose bits vs the oracle."""
+    rt = _host_rt(pkg, 921600, 1, 0)
+    try:
+        rt.ResetDosageMap()
+        for _ in range(4):
+            rt.ComputeDosageMap()
+            rt.Shade()
+            rt.currIterations = rt.currIterations + 1
+        dose = rt.read_dosage()
+        assert rt.photonsPerLight == 921600 and rt.photonMapSize == 4 * 921600
+    finally:
+        rt.close()
+    comp = orc.Computation(oscene, oroute["lamps"][:1], 921600, oroute["lightHeight"], oroute["lightLength"],
+                           oroute["lightIntensity"])
+    comp.reset()
+    for _ in range(4):
+        comp.iteration()
+    assert np.array_equal(bits(dose), bits(comp.dose())) and (dose != 0).sum() > 20000

@@ -75,7 +75,15 @@ def test_calibrate_power_then_compute(host, orc, oscene, oroute):
     rt.set_lamps(rt.lamps()[:1])
     rt.photonCount = 400000
     rt.maxIterations = 3
+    # colours on screen before the calibration (the reference keeps them: ClearBuffers(false), raytracer.cpp:187,224)
+    rt.ResetDosageMap()
+    rt.ComputeDosageMap()
+    rt.Shade()
+    colours = rt.ctx.read_color()
+    assert colours.any()
+    rt.ctx.seed = 0
     rt.CalibratePower(2909.0, 0.8, 1.0)      # userinterface.cpp:107-109 defaults
+    assert np.array_equal(bits(rt.ctx.read_color()), bits(colours))
     power, seed, dose = oracle_calibrate(orc, oscene.floorHeight, oroute["lightHeight"], oroute["lightLength"],
                                          400000, 3, 2909.0, 0.8, 1.0, 0)
     assert dose.min() > 0
