@@ -13,11 +13,12 @@ fit in L2.
 
 One STEP = one whole computation: ResetDosageMap, then per wave generate -> extend -> accumulate and Shade
 (computeDosage + dosageToColor), then a sync.  Inputs (scene, BVH) are resident in HBM before the timed region.
-`--mode loop` (default at N = 1) is the reference's host loop call by call (myapp.cpp:156-163) with the
-library's two-stream launch pipelining; `--mode batched` runs it as RayTracer::ComputeIterationsBatched
-(include/uvrt.h "batched tracing": the waves traced first in fused launches of a few waves each, then
-accumulate + Shade replayed per wave: the same arithmetic, the same bits).  Both are timed at N = 1; `value`
-is the selected mode's, the other one is reported under `other_modes`.
+`--mode batched` (default) runs it as RayTracer::ComputeIterationsBatched (include/uvrt.h "batched tracing": the
+waves traced first in fused launches of a few waves each on two side streams, then accumulate + Shade replayed
+per wave on the context's stream while the next computation is already being traced: the same arithmetic, the
+same bits); `--mode loop` is the reference's host loop call by call (myapp.cpp:156-163) with the library's
+two-stream launch pipelining.  Both are timed at N = 1; `value` is the selected mode's, the other one is
+reported under `other_modes`.
 
 N > 1 (one process per GPU): STRONG scaling is the headline -- BASELINE configs[3]: every launch is split by
 global-id range over the ranks ("pixel tiles"), each rank deposits into private int32 planes, ONE RCCL
@@ -144,9 +145,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--photons", type=int, default=PHOTONS)
     ap.add_argument("--waves", type=int, default=WAVES, help="waves (iterations) of the computation")
-    ap.add_argument("--mode", choices=["batched", "loop"], default=None,
-                    help="N = 1: loop (default) = the reference's host loop call by call; batched = RayTracer::"
-                         "ComputeIterationsBatched.  N > 1 always runs the batched, sharded computation")
+    ap.add_argument("--mode", choices=["batched", "loop"], default="batched",
+                    help="N = 1: batched (default) = RayTracer::ComputeIterationsBatched; loop = the reference's host loop "
+                         "call by call.  N > 1 always runs the batched, sharded computation")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1 headline: strong (default, BASELINE configs[3]: launches split by global-id range, one "
                          "int32 all-reduce of the count planes per computation) or weak (configs[4]: whole launches dealt "
@@ -180,8 +181,6 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     if world > 1 and args.mode == "loop":
         raise SystemExit("--mode loop is a single-GPU mode (N > 1 runs the sharded batched computation)")
-    if args.mode is None:
-        args.mode = "loop" if world == 1 else "batched"
     ndev = torch.cuda.device_count()
     rehearsal = world > ndev          # more ranks than GPUs: ranks share devices, collectives over gloo
     dev_index = local_rank % ndev

@@ -141,8 +141,16 @@ struct uvrt_ctx {
 
     // Batched tracing (uvrt_trace_batch): the rays of up to MAX_BATCH launches side by side, one count
     // "plane" (replicas x T ints) per launch, one per-launch record array per distinct lamp.
-    DevBuf b_rays, b_planes, b_folded;
+    // two buffer sets: batch k + 1 is traced (on the launch lanes) into one while batch k is folded, reduced and
+    // replayed (on the context's stream) out of the other
+    struct BatchSet { DevBuf rays, planes, folded; hipEvent_t free_ev = nullptr; };
+    BatchSet bs[2];
+    int b_set = 0;                        // the set of the traced batch (b_count > 0) / of the last one
+    uint64_t b_chunks = 0;                // chunks traced so far: consecutive chunks alternate over the launch lanes
+    int32_t b_repl = 64;                  // deposit replicas per plane of the traced batch
     std::vector<DevBuf> b_recs;           // [group]
+    struct RecsKey { float ox = 0, oz = 0; const uint32_t* perm = nullptr; bool valid = false; };
+    std::vector<RecsKey> b_recs_key;      // what b_recs[g] holds
     int32_t b_count = 0;                  // launches of the batch that has not been replayed (0: none)
     int64_t b_n = 0, b_npad = 0;
     int32_t b_phys[MAX_BATCH] = {};       // logical launch -> physical plane (launches are grouped by lamp)
@@ -403,7 +411,10 @@ void uvrt_destroy(uvrt_ctx* c)
     for (DevBuf& b : c->recs4) b.release();
     for (DevBuf& b : c->b_recs) b.release();
     for (auto& h : c->hot) { h.perm.release(); h.hist.release(); (void)hipEventDestroy(h.ready); }
-    for (DevBuf* b : {&c->b_rays, &c->b_planes, &c->b_folded}) b->release();
+    for (auto& bset : c->bs) {
+        for (DevBuf* b : {&bset.rays, &bset.planes, &bset.folded}) b->release();
+        if (bset.free_ev) (void)hipEventDestroy(bset.free_ev);
+    }
     for (DevBuf* b : {&c->pairs, &c->recs, &c->perm, &c->ltris, &c->leaf_count, &c->area, &c->photon_map, &c->max_map,
                       &c->counts, &c->dosage, &c->color, &c->rays, &c->keyrank, &c->sorted,
                       &c->order, &c->hits, &c->hist, &c->bin_start, &c->export_buf,
@@ -643,7 +654,8 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
     c->b_is_folded = false;
     for (DevBuf& b : c->b_recs) b.release();
     c->b_recs.clear();
-    for (DevBuf* b : {&c->b_planes, &c->b_folded}) b->release();
+    c->b_recs_key.clear();
+    for (auto& bset : c->bs) for (DevBuf* b : {&bset.planes, &bset.folded}) b->release();
     return UVRT_OK;
 }
 
@@ -689,11 +701,11 @@ int uvrt_reset(uvrt_ctx* c, int32_t reset_color)
     }
     c->counts_dirty[0] = false;
     if (c->b_count > 0) {     // a traced batch that was never replayed: drop its deposits
-        if (c->b_is_folded) HIP_TRY(hipMemsetAsync(c->b_folded.p, 0, c->b_folded.bytes, c->stream));
-        else HIP_TRY(hipMemsetAsync(c->b_planes.p, 0, c->b_planes.bytes, c->stream));
+        if (c->b_is_folded) HIP_TRY(hipMemsetAsync(c->bs[c->b_set].folded.p, 0, c->bs[c->b_set].folded.bytes, c->stream));
+        else HIP_TRY(hipMemsetAsync(c->bs[c->b_set].planes.p, 0, c->bs[c->b_set].planes.bytes, c->stream));
+        HIP_TRY(hipEventRecord(c->bs[c->b_set].free_ev, c->stream));
         c->b_count = 0;
         c->b_is_folded = false;
-        dirty = true;
     }
     return dirty ? mark_fence(c) : mark_map_fence(c);
 }
@@ -1087,7 +1099,11 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
         return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: per-ray hit records and ray ordering are per-launch features");
     if (int rc = set_device(c)) return rc;
     const int64_t n_pad = (n + 63) / 64 * 64;
-    const int R = c->replicas;
+    // deposit replicas per plane: the contention on a hot triangle's counter grows with the rays per plane
+    // (64 replicas for 2 M rays; measured in profiles/r01_v6_experiments.txt), and every replica is read and
+    // zeroed again by the replay -- a shard of a launch gets by with proportionally fewer
+    int R = c->replicas;
+    while (R > 4 && (int64_t)R * 32768 > 2 * n) R >>= 1;
     if ((uint64_t)count * (uint64_t)n_pad >= ((uint64_t)1 << 30) || (uint64_t)count * (uint64_t)R * (uint64_t)c->T >= ((uint64_t)1 << 32))
         return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: %d launches x %lld rays exceed one batch (2^30 ray slots, 2^32 counters)", count, (long long)n);
 
@@ -1118,41 +1134,63 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
         }
         c->seed = seed;
     }
-    // everything outstanding first (the batch buffers may be re-allocated, the lanes are re-used)
-    if (int rc = join_all(c)) return rc;
+    // The batch goes into the buffer set the previous batch did NOT use: its lanes start at once -- in the drain of
+    // the previous batch, while that one is still being folded / reduced / replayed on the context's stream -- and
+    // only wait for the set's last replay (free_ev), which is two batches back.  Anything that has to touch memory
+    // the lanes may still read (growing a buffer, new per-launch records) first waits for everything.
+    const int set = c->b_set ^ 1;
+    uvrt_ctx::BatchSet& S = c->bs[set];
     int rc;
     const size_t plane_ints = (size_t)R * (size_t)c->T;
-    if (c->b_rays.bytes < (size_t)count * (size_t)n_pad * 16 || c->b_planes.bytes < (size_t)count * plane_ints * 4 ||
-        c->b_folded.bytes < (size_t)count * (size_t)c->T * 4 || (int)c->b_recs.size() < ngroups)
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = c->b_rays.ensure((size_t)count * (size_t)n_pad * 16, false, c->stream))) return rc;
-    if ((rc = c->b_planes.ensure((size_t)count * plane_ints * 4, true, c->stream))) return rc;
-    if ((rc = c->b_folded.ensure((size_t)count * (size_t)c->T * 4, true, c->stream))) return rc;
-    while ((int)c->b_recs.size() < ngroups) {
-        DevBuf b;
-        if ((rc = b.ensure(((size_t)c->npairs + (size_t)c->T + 1) * 64, true, c->stream))) return rc;
-        launch_prepare_leaves6(c->ltris.as<LeafTri>(), b.p, c->npairs, c->T, c->stream);
-        c->b_recs.push_back(b);
-    }
-    for (int l = 1; l < c->nlanes; ++l)
-        if ((rc = c->xovf[l].ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream))) return rc;
-
-    // Per-launch records of every lamp column on the main stream, then the launches in CHUNKS of a few planes:
-    // generate + fused extend of a chunk on one launch lane, chunks alternating over the lanes.  A chunk's rays
-    // (16 B each) are sized to stay in the Infinity Cache between the generate that writes them and the extend
-    // that reads them (a refill that has to go to HBM stalls its wave for microseconds), and the next chunk's
-    // generate and first waves run in the drain of the previous one.
+    // full planes are allocated for the context's replica count: R only shrinks the part of it that is used
+    const size_t plane_alloc = (size_t)c->replicas * (size_t)c->T;
+    bool need_sync = S.rays.bytes < (size_t)count * (size_t)n_pad * 16 || S.planes.bytes < (size_t)count * plane_alloc * 4 ||
+                     S.folded.bytes < (size_t)count * (size_t)c->T * 4 || (int)c->b_recs.size() < ngroups || !S.free_ev;
     const uint32_t* gperm[MAX_BATCH] = {};
     for (int g = 0; g < ngroups; ++g) {
-        const int ph = gfirst[g];          // the group's first launch lends its lamp and seeds to the statistics
-        const float gl[3] = {gp.lx[ph], gp.ly[ph], gp.lz[ph]};
         gperm[g] = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
-        if (!gperm[g] && (int64_t)gsize[g] * n >= 16384)
+        if (!gperm[g] && (int64_t)gsize[g] * n >= 16384) {
+            const int ph = gfirst[g];      // the group's first launch lends its lamp and seeds to the statistics
+            const float gl[3] = {gp.lx[ph], gp.ly[ph], gp.lz[ph]};
             if (int rcp = launch_perm(c, gl, light_length, gp.seed_prev[ph], gp.seed_next[ph], 32768, c->stream, &gperm[g])) return rcp;
-        launch_prepare_launch6(c->pairs.as<PairRec>(), c->b_recs[g].p, gx[g], gz[g], c->npairs, gperm[g], c->stream);
+        }
+        if (g >= (int)c->b_recs_key.size() || c->b_recs_key[g].perm != gperm[g] || memcmp(&c->b_recs_key[g].ox, &gx[g], 4) != 0 ||
+            memcmp(&c->b_recs_key[g].oz, &gz[g], 4) != 0)
+            need_sync = true;
     }
-    HIP_TRY(hipGetLastError());
-    if (int rcf = mark_fence(c)) return rcf;         // the lanes' next work waits for the records (and the reset before)
+    if (need_sync) {
+        if (int rcj = join_all(c)) return rcj;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!S.free_ev) HIP_TRY(hipEventCreateWithFlags(&S.free_ev, hipEventDisableTiming));
+        const bool grown = S.planes.bytes < (size_t)count * plane_alloc * 4 || S.folded.bytes < (size_t)count * (size_t)c->T * 4;
+        if ((rc = S.rays.ensure((size_t)count * (size_t)n_pad * 16, false, c->stream))) return rc;
+        if ((rc = S.planes.ensure((size_t)count * plane_alloc * 4, true, c->stream))) return rc;
+        if ((rc = S.folded.ensure((size_t)count * (size_t)c->T * 4, true, c->stream))) return rc;
+        if (grown) HIP_TRY(hipEventRecord(S.free_ev, c->stream));      // the zero fill is the set's "last replay"
+        while ((int)c->b_recs.size() < ngroups) {
+            DevBuf b;
+            if ((rc = b.ensure(((size_t)c->npairs + (size_t)c->T + 1) * 64, true, c->stream))) return rc;
+            launch_prepare_leaves6(c->ltris.as<LeafTri>(), b.p, c->npairs, c->T, c->stream);
+            c->b_recs.push_back(b);
+        }
+        c->b_recs_key.resize(c->b_recs.size());
+        for (int l = 1; l <= 2; ++l)
+            if ((rc = c->xovf[l].ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream))) return rc;
+        // per-launch records of the lamp columns whose array holds something else
+        for (int g = 0; g < ngroups; ++g) {
+            uvrt_ctx::RecsKey& key = c->b_recs_key[g];
+            if (key.perm == gperm[g] && key.valid && memcmp(&key.ox, &gx[g], 4) == 0 && memcmp(&key.oz, &gz[g], 4) == 0) continue;
+            launch_prepare_launch6(c->pairs.as<PairRec>(), c->b_recs[g].p, gx[g], gz[g], c->npairs, gperm[g], c->stream);
+            key.ox = gx[g]; key.oz = gz[g]; key.perm = gperm[g]; key.valid = true;
+        }
+        HIP_TRY(hipGetLastError());
+        if (int rcf = mark_fence(c)) return rcf;         // the lanes' next work waits for the records
+    }
+    // Launches in CHUNKS of a few planes: generate + fused extend of a chunk on one launch lane, chunks alternating
+    // over the lanes.  A chunk's rays (16 B each) are sized to stay in the Infinity Cache between the generate
+    // that writes them and the extend that reads them (a refill that has to go to HBM stalls its wave for
+    // microseconds), and the next chunk's generate and first waves run in the drain of the previous one.
+    bool lane_waited[uvrt_ctx::MAXL] = {};
     size_t chunk_bytes = (size_t)96 << 20;
     if (const char* e = getenv("UVRT_BATCH_CHUNK_MB")) { const long v = atol(e); if (v > 0) chunk_bytes = (size_t)v << 20; }
     const int per_chunk = (int)std::max<size_t>(1, chunk_bytes / ((size_t)n_pad * 16));
@@ -1161,12 +1199,18 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     for (int g = 0; g < ngroups; ++g) {
         for (int k0 = 0; k0 < gsize[g]; k0 += per_chunk, ++chunk_index) {
             const int kc = std::min(per_chunk, gsize[g] - k0), ph0 = gfirst[g] + k0;
-            c->lane = (c->pipeline && c->nlanes > 1) ? chunk_index % c->nlanes : 0;
+            // two SIDE lanes in turn: the context's own stream carries the fold / reduce / replay of the previous batch,
+            // which a chunk enqueued there would have to wait for
+            c->lane = c->pipeline ? 1 + (int)(c->b_chunks++ & 1u) : 0;
             hipStream_t ls;
             if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }
+            if (!lane_waited[c->lane]) {      // the set's previous occupant has been replayed (two batches back)
+                HIP_TRY(hipStreamWaitEvent(ls, S.free_ev, 0));
+                lane_waited[c->lane] = true;
+            }
             GenBatchParams gq;
             memset(&gq, 0, sizeof gq);
-            gq.rays = c->b_rays.as<float4>() + (size_t)ph0 * (size_t)n_pad;
+            gq.rays = S.rays.as<float4>() + (size_t)ph0 * (size_t)n_pad;
             gq.n_pad = n_pad;
             gq.first_gid = first_gid;
             gq.n = n;
@@ -1197,7 +1241,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.num_cus = c->num_cus;
             p.flavour = c->flavour;
             p.top_pairs = c->top_pairs;
-            p.counts = c->b_planes.as<int32_t>() + (size_t)ph0 * plane_ints;
+            p.counts = S.planes.as<int32_t>() + (size_t)ph0 * plane_ints;
             p.count_replicas = R;
             p.count_stride = c->T;
             p.error_flag = c->error_flag.as<uint32_t>();
@@ -1238,6 +1282,8 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     c->lane = 0;
     c->cur_pipelined = false;
     c->last_n = -1;                      // the per-launch generate/extend pairing starts afresh
+    c->b_set = set;
+    c->b_repl = R;
     c->b_count = count;
     c->b_n = n;
     c->b_npad = n_pad;
@@ -1251,10 +1297,10 @@ int uvrt_fold_batch(uvrt_ctx* c)
     if (c->b_is_folded) return UVRT_OK;
     if (int rc = set_device(c)) return rc;
     if (int rc = join_all(c)) return rc;
-    launch_fold_planes(c->b_planes.as<int32_t>(), c->b_folded.as<int32_t>(), c->b_count, c->replicas, c->T, c->stream);
+    launch_fold_planes(c->bs[c->b_set].planes.as<int32_t>(), c->bs[c->b_set].folded.as<int32_t>(), c->b_count, c->b_repl, c->T, c->stream);
     HIP_TRY(hipGetLastError());
     c->b_is_folded = true;
-    return mark_fence(c);
+    return UVRT_OK;          // on the context's stream like everything else that touches the set until its replay
 }
 
 int uvrt_replay_batch(uvrt_ctx* c, const uvrt_replay_op* ops, int32_t count, int32_t tri_count)
@@ -1268,13 +1314,13 @@ int uvrt_replay_batch(uvrt_ctx* c, const uvrt_replay_op* ops, int32_t count, int
     memset(&p, 0, sizeof p);
     p.photon_map = c->photon_map.as<double>();
     p.max_map = c->max_map.as<double>();
-    p.planes = c->b_planes.as<int32_t>();
-    p.folded = c->b_folded.as<int32_t>();
+    p.planes = c->bs[c->b_set].planes.as<int32_t>();
+    p.folded = c->bs[c->b_set].folded.as<int32_t>();
     p.dosage = c->dosage.as<float>();
     p.color = c->color.as<float>();
     p.area = c->area.as<float>();
-    p.plane_stride = (int64_t)c->replicas * c->T;
-    p.replicas = c->replicas;
+    p.plane_stride = (int64_t)c->b_repl * c->T;
+    p.replicas = c->b_repl;
     p.T = tri_count;
     p.count = count;
     p.is_folded = c->b_is_folded ? 1 : 0;
@@ -1293,12 +1339,14 @@ int uvrt_replay_batch(uvrt_ctx* c, const uvrt_replay_op* ops, int32_t count, int
     launch_replay_batch(p, c->stream);
     HIP_TRY(hipGetLastError());
     if (tri_count < c->T) {     // a partial replay (calibration's 2-triangle scene never does this): clear the rest
-        if (c->b_is_folded) HIP_TRY(hipMemsetAsync(c->b_folded.p, 0, c->b_folded.bytes, c->stream));
-        else HIP_TRY(hipMemsetAsync(c->b_planes.p, 0, c->b_planes.bytes, c->stream));
+        if (c->b_is_folded) HIP_TRY(hipMemsetAsync(c->bs[c->b_set].folded.p, 0, c->bs[c->b_set].folded.bytes, c->stream));
+        else HIP_TRY(hipMemsetAsync(c->bs[c->b_set].planes.p, 0, c->bs[c->b_set].planes.bytes, c->stream));
     }
+    HIP_TRY(hipEventRecord(c->bs[c->b_set].free_ev, c->stream));    // the set may be traced into again
     c->b_count = 0;
     c->b_is_folded = false;
-    return mark_fence(c);
+    // later accumulate / Shade work waits for this replay; the next batch's generate / extend do not
+    return mark_map_fence(c);
 }
 
 int uvrt_read_batch_counts(uvrt_ctx* c, int32_t launch, int32_t* out, int32_t first, int32_t count)
@@ -1308,7 +1356,7 @@ int uvrt_read_batch_counts(uvrt_ctx* c, int32_t launch, int32_t* out, int32_t fi
     if (int rc = uvrt_fold_batch(c)) return rc;
     if (!out || first < 0 || count < 0 || first + count > c->T) return fail(UVRT_ERR_INVALID, "uvrt_read_batch_counts: bad range");
     if (count == 0) return UVRT_OK;
-    HIP_TRY(hipMemcpyAsync(out, c->b_folded.as<int32_t>() + (size_t)c->b_phys[launch] * c->T + first, (size_t)count * 4,
+    HIP_TRY(hipMemcpyAsync(out, c->bs[c->b_set].folded.as<int32_t>() + (size_t)c->b_phys[launch] * c->T + first, (size_t)count * 4,
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return UVRT_OK;
@@ -1429,9 +1477,9 @@ int uvrt_reduce_batch(uvrt_ctx* c)
     if (!c->comm) return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch: no communicator (uvrt_comm_init_rank / uvrt_comm_init_all)");
     if (int rc = uvrt_fold_batch(c)) return rc;
     if (int rc = set_device(c)) return rc;
-    RCCL_TRY(g_rccl.AllReduce(c->b_folded.p, c->b_folded.p, (size_t)c->b_count * (size_t)c->T, ncclInt32, ncclSum,
+    RCCL_TRY(g_rccl.AllReduce(c->bs[c->b_set].folded.p, c->bs[c->b_set].folded.p, (size_t)c->b_count * (size_t)c->T, ncclInt32, ncclSum,
                               (ncclComm_t)c->comm, c->stream));
-    return mark_fence(c);
+    return UVRT_OK;
 }
 
 int uvrt_reduce_batch_group(uvrt_ctx** ctxs, int32_t n)
@@ -1450,11 +1498,10 @@ int uvrt_reduce_batch_group(uvrt_ctx** ctxs, int32_t n)
         for (int i = 0; i < n; ++i) {
             if (!ctxs[i]->comm) { (void)g_rccl.GroupEnd(); return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: context %d has no communicator", i); }
             HIP_TRY(hipSetDevice(ctxs[i]->device));
-            RCCL_TRY(g_rccl.AllReduce(ctxs[i]->b_folded.p, ctxs[i]->b_folded.p, count, ncclInt32, ncclSum,
+            RCCL_TRY(g_rccl.AllReduce(ctxs[i]->bs[ctxs[i]->b_set].folded.p, ctxs[i]->bs[ctxs[i]->b_set].folded.p, count, ncclInt32, ncclSum,
                                       (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream));
         }
         RCCL_TRY(g_rccl.GroupEnd());
-        for (int i = 0; i < n; ++i) if (int rc = mark_fence(ctxs[i])) return rc;
         return UVRT_OK;
     }
     // contexts of ONE device (rehearsals, tests): sum on context 0's stream, hand the result to the others
@@ -1466,17 +1513,16 @@ int uvrt_reduce_batch_group(uvrt_ctx** ctxs, int32_t n)
     for (int i = 1; i < n; ++i) {
         HIP_TRY(hipEventRecord(ctxs[i]->ev_tail[0], ctxs[i]->stream));
         HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev_tail[0], 0));
-        launch_add_counts(c0->b_folded.as<int32_t>(), ctxs[i]->b_folded.as<int32_t>(), (int64_t)count, c0->stream);
+        launch_add_counts(c0->bs[c0->b_set].folded.as<int32_t>(), ctxs[i]->bs[ctxs[i]->b_set].folded.as<int32_t>(), (int64_t)count, c0->stream);
     }
     HIP_TRY(hipGetLastError());
     for (int i = 1; i < n; ++i)
-        HIP_TRY(hipMemcpyAsync(ctxs[i]->b_folded.p, c0->b_folded.p, count * 4, hipMemcpyDeviceToDevice, c0->stream));
+        HIP_TRY(hipMemcpyAsync(ctxs[i]->bs[ctxs[i]->b_set].folded.p, c0->bs[c0->b_set].folded.p, count * 4, hipMemcpyDeviceToDevice, c0->stream));
     HIP_TRY(hipEventRecord(c0->ev_tail[0], c0->stream));
     for (int i = 1; i < n; ++i) {
         HIP_TRY(hipStreamWaitEvent(ctxs[i]->stream, c0->ev_tail[0], 0));
-        if (int rc = mark_fence(ctxs[i])) return rc;
     }
-    return mark_fence(c0);
+    return UVRT_OK;
 }
 
 int uvrt_advance_seed(uvrt_ctx* c, const float lp[3], float light_length)
@@ -1620,7 +1666,7 @@ int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
         case 5:
             if (c->b_count <= 0) return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: no traced batch");
             if (int rc = uvrt_fold_batch(c)) return rc;
-            b = &c->b_folded; elem = 4 * (size_t)c->b_count;
+            b = &c->bs[c->b_set].folded; elem = 4 * (size_t)c->b_count;
             break;
         default: return fail(UVRT_ERR_INVALID, "uvrt_device_ptr: which must be 0..5");
     }
@@ -1628,7 +1674,8 @@ int uvrt_device_ptr(uvrt_ctx* c, int32_t which, void** ptr, int64_t* bytes)
     *bytes = (int64_t)((size_t)c->T * elem);
     // see lane_stream(): the next side-lane work (on the maps: the next accumulate / Shade) waits for
     // what the caller enqueues on the main stream up to the next call
-    if (which == 2 || which == 5) c->ext_touch = true; else c->ext_touch_maps = true;
+    // (the folded planes of a batch are only touched on the context's stream until their replay: no fence)
+    if (which == 2) c->ext_touch = true; else if (which != 5) c->ext_touch_maps = true;
     return UVRT_OK;
 }
 

@@ -33,7 +33,7 @@ def test_two_rank_rehearsal_matches_single_rank():
     one = bench(common + ["--waves", "6"])
     two = bench(common + ["--waves", "6"], ranks=2, port=29531)        # strong headline; weak: 2 ranks x 6 waves
     three = bench(common + ["--waves", "6", "--scaling", "weak"], ranks=3, port=29532)
-    assert one["other_modes"]["batched"]["dose_crc32"] == one["dose_crc32"] and one["config"]["mode"] == "loop"
+    assert one["other_modes"]["loop"]["dose_crc32"] == one["dose_crc32"] and one["config"]["mode"] == "batched"
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and three["scaling"] == "weak"
     for d in (two, three):
         assert d["multi_gpu_check"]["dose_identical_on_all_ranks"]
