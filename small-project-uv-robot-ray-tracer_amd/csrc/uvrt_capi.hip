@@ -914,13 +914,15 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     }
     if (c->variant >= 500 && c->variant < 600) p.force_exact = 1;
     p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
-    static const int per_cu[5] = {8, 4, 6, 2, 16};
+    static const int per_cu[6] = {8, 4, 6, 2, 16, 7};
     const int gcode = (c->variant / 10) % 10;
     const int code6 = c->variant == 0 ? 1 : c->variant % 10;   // default: LDS top cache, leaf visits every 2nd trip
-    // default grid: 8 workgroups per CU on one stream; with four launch lanes 4 per CU (two launches
-    // co-resident fill the GPU, every wave owns twice the rays: a shorter drain per ray)
-    const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : 8;
-    if (!launch_extend6(p, code6, c->variant == 0 ? per_cu_default : per_cu[gcode < 5 ? gcode : 0], ls))
+    // default grid: 8 workgroups per CU on one stream; 7 when launches are pipelined over several streams -- the
+    // free wave slot per CU lets the small kernels of the neighbouring launch (generate, accumulate, replay) run at
+    // once instead of queueing behind persistent waves (+1-2 %, profiles/r02_experiments.txt); with four launch
+    // lanes 4 per CU
+    const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : c->cur_pipelined ? 7 : 8;
+    if (!launch_extend6(p, code6, c->variant == 0 ? per_cu_default : per_cu[gcode < 6 ? gcode : 0], ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, ls));
@@ -1256,7 +1258,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.plane_batches = (uint32_t)(n_pad / 64);
             p.plane_n = (uint32_t)n;
             p.plane_stride = (uint32_t)plane_ints;
-            static const int per_cu[5] = {8, 4, 6, 2, 16};
+            static const int per_cu[6] = {8, 4, 6, 2, 16, 7};
             const int gcode = (c->variant / 10) % 10;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->timing) {
@@ -1271,7 +1273,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                 ++c->ev_used;
                 HIP_TRY(hipEventRecord(e0, ls));
             }
-            if (!launch_extend6(p, c->variant == 0 ? 1 : c->variant % 10, c->variant == 0 ? 8 : per_cu[gcode < 5 ? gcode : 0], ls)) {
+            if (!launch_extend6(p, c->variant == 0 ? 1 : c->variant % 10, c->variant == 0 ? (c->pipeline ? 7 : 8) : per_cu[gcode < 6 ? gcode : 0], ls)) {
                 c->lane = lane_before;
                 return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: variant %d needs a larger overflow-stack buffer", c->variant);
             }
