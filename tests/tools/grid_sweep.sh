@@ -1,4 +1,4 @@
-for v in 0 621 651 611; do for m in batched loop; do
+for v in ${VARIANTS:-0 621 651 611}; do for m in batched loop; do
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --variant $v --mode $m 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
