@@ -154,6 +154,9 @@ def main():
                          "to ranks, 8 waves per GPU); the other one is measured too and reported beside it")
     ap.add_argument("--scene", default=None, help="a .glb file, or soup:T for a synthetic T-triangle scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling aid: only the headline mode (no other-mode leg, no single-computation leg), so that a "
+                         "kernel trace / PMC run holds nothing but the timed kind of launch")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: launches do not overlap")
     ap.add_argument("--sort-bits", type=int, default=None)
     ap.add_argument("--variant", type=int, default=None)
@@ -334,20 +337,21 @@ def main():
         # one computation on its own, bracketed by syncs (the reference syncs every iteration, myapp.cpp:165;
         # `value` is the steady-state rate of back-to-back computations)
         sm = []
-        for _ in range(max(1, min(5, args.steps))):
+        for _ in range(0 if args.lean else max(1, min(5, args.steps))):
             sync_all()
             t1 = time.perf_counter()
             headline()
             sync_all()
             sm.append((time.perf_counter() - t1) * 1e3)
         sm.sort()
-        single_ms = sm[len(sm) // 2]
+        single_ms = sm[len(sm) // 2] if sm else None
         # the other mode, for comparison, and its dose
-        other = step_loop if args.mode == "batched" else step_batched
-        el_o = timed(other, args.warmup, args.steps)
-        other_modes["loop" if args.mode == "batched" else "batched"] = {
-            "value": round(rays_per_step * args.steps / el_o / 1e6, 2), "ms_per_step": round(el_o / args.steps * 1e3, 4),
-            "dose_crc32": crc(rt.read_dosage())}
+        if not args.lean:
+            other = step_loop if args.mode == "batched" else step_batched
+            el_o = timed(other, args.warmup, args.steps)
+            other_modes["loop" if args.mode == "batched" else "batched"] = {
+                "value": round(rays_per_step * args.steps / el_o / 1e6, 2), "ms_per_step": round(el_o / args.steps * 1e3, 4),
+                "dose_crc32": crc(rt.read_dosage())}
         # timing pass for the roofline: the headline step with HIP events around the extend launches on their
         # stream (loop mode: launch pipelining off, so the kernels of neighbouring waves do not overlap)
         if args.mode == "loop":
@@ -519,8 +523,9 @@ def main():
         if world == 1:
             if crc(dose_after) != crc_timed or any(v["dose_crc32"] != crc_timed for v in other_modes.values()):
                 raise SystemExit("bench: the passes disagree on the dose (%s / %s / %s)" % (crc_timed, other_modes, crc(dose_after)))
-            out["single_computation"] = {"ms": round(single_ms, 4), "mray_s": round(rays_per_step / single_ms / 1e3, 1),
-                                         "note": "one step bracketed by device syncs, median of %d" % max(1, min(5, args.steps))}
+            if single_ms is not None:
+                out["single_computation"] = {"ms": round(single_ms, 4), "mray_s": round(rays_per_step / single_ms / 1e3, 1),
+                                             "note": "one step bracketed by device syncs, median of %d" % max(1, min(5, args.steps))}
             out["other_modes"] = other_modes
         else:
             out["multi_gpu_check"] = {"dose_identical_on_all_ranks": ranks_agree, "photons_traced": rays_per_step}
