@@ -229,3 +229,40 @@ def test_baseline_config_1_shape_host_loop(pkg, orc, oscene, oroute):
     for _ in range(4):
         comp.iteration()
     assert np.array_equal(bits(dose), bits(comp.dose())) and (dose != 0).sum() > 20000
+
+
+def test_batch_of_64_launches_many_lamp_columns_and_chunks(pkg, orc, oscene, oroute, monkeypatch):
+    """The largest batch (64 launches) over all 12 lamps of lange_route.xml in a scrambled order (12 lamp columns,
+    5-6 launches each), with the chunk size forced down so that every column is traced in several chunks; the
+    per-launch counts of a sample of launches against the oracle, the maps against the per-launch replay on the CPU."""
+    monkeypatch.setenv("UVRT_BATCH_CHUNK_MB", "1")           # 1 MB = 2 planes of 20 011 rays (n_pad 20 032 x 16 B)
+    n = 20011
+    rng = np.random.default_rng(11)
+    order = [int(x) for x in rng.integers(0, 12, 64)]
+    lamps = [lamp_pos(orc, oscene, oroute, k) for k in order]
+    durations = [float(d) for d in rng.integers(1, 90, 64)]
+    c = pkg.capi.Ctx(0)
+    try:
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        c.reset(True)
+        c.seed = 5
+        c.trace_batch(lamps, oroute["lightLength"], 3, n)
+        planes = [c.read_batch_counts(k) for k in range(64)]
+        c.replay_batch(make_ops(pkg, durations, {63: 0}, n))
+        pm, mm = c.read_photon_map(0), c.read_photon_map(1)
+    finally:
+        c.close()
+    seed = 5
+    want_pm, want_mm = np.zeros(oscene.T), np.zeros(oscene.T)
+    for k in range(64):
+        if k in (0, 17, 40, 63):
+            rays, nxt = orc.generate(3, n, lamps[k], oroute["lightLength"], seed)
+            temp = np.zeros(oscene.T, dtype=np.int32)
+            orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+            assert np.array_equal(temp, planes[k]), k
+        else:
+            nxt = pkg.capi.seed_next(lamps[k], oroute["lightLength"], seed)
+        seed = nxt
+        cnt = planes[k].copy()
+        orc.accumulate(want_pm, want_mm, cnt, durations[k])
+    assert np.array_equal(bits64(pm), bits64(want_pm)) and np.array_equal(bits64(mm), bits64(want_mm)) and pm.any()
