@@ -266,3 +266,55 @@ def test_batch_of_64_launches_many_lamp_columns_and_chunks(pkg, orc, oscene, oro
         cnt = planes[k].copy()
         orc.accumulate(want_pm, want_mm, cnt, durations[k])
     assert np.array_equal(bits64(pm), bits64(want_pm)) and np.array_equal(bits64(mm), bits64(want_mm)) and pm.any()
+
+
+def test_batches_and_single_launches_interleave_on_one_context(pkg, orc, oscene, oroute):
+    """The same twelve launches (4 lamps x 3 iterations) as (a) single launches, (b) batch / single launches / batch
+    mixed on one context, with read-backs in between: maps, dose, colours and SEED identical at the end, and the
+    read-backs in the middle equal the single-launch sequence at the same point."""
+    length = oroute["lightLength"]
+    n = 50003
+    lamps4 = [lamp_pos(orc, oscene, oroute, k) for k in (2, 6, 7, 10)]
+    seq = [(lamps4[k % 4], 10.0 + k) for k in range(12)]
+    a = pkg.capi.Ctx(0)
+    b = pkg.capi.Ctx(0)
+    try:
+        for c in (a, b):
+            c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+            c.resize_rays(n)
+            c.reset(True)
+        mid_a = {}
+        for k, (lp, d) in enumerate(seq):
+            a.generate(lp, length, 0, n)
+            a.extend(n)
+            a.accumulate(d)
+            if k in (4, 7):
+                mid_a[k] = a.read_photon_map(0)
+        a.shade(0, 3 * n, 44.0, 100.0, 0)
+
+        def ops_for(part, shade_last=False):
+            ops = np.zeros(len(part), dtype=pkg.capi.REPLAY_OP_DT)
+            for j, (_, d) in enumerate(part):
+                ops[j] = (d, 0, 0, 1, 1.0, 1.0, 0)
+            if shade_last:
+                ops[-1] = (part[-1][1], 1, 0, 3 * n, 44.0, 100.0, 0)
+            return ops
+
+        b.trace_batch([lp for lp, _ in seq[:5]], length, 0, n)
+        b.replay_batch(ops_for(seq[:5]))
+        assert np.array_equal(bits64(b.read_photon_map(0)), bits64(mid_a[4]))
+        for lp, d in seq[5:8]:                      # three single launches (pipelined lanes) in between
+            b.generate(lp, length, 0, n)
+            b.extend(n)
+            b.accumulate(d)
+        assert np.array_equal(bits64(b.read_photon_map(0)), bits64(mid_a[7]))
+        b.trace_batch([lp for lp, _ in seq[8:]], length, 0, n)
+        b.replay_batch(ops_for(seq[8:], shade_last=True))
+        assert a.seed == b.seed
+        for w in (0, 1):
+            assert np.array_equal(bits64(b.read_photon_map(w)), bits64(a.read_photon_map(w)))
+        assert np.array_equal(bits(b.read_dosage()), bits(a.read_dosage())) and a.read_dosage().any()
+        assert np.array_equal(bits(b.read_color()), bits(a.read_color()))
+    finally:
+        a.close()
+        b.close()
