@@ -137,10 +137,128 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
     }
 }
 
+// The same step for the common case -- no lane needs the IEEE-division form, no lane's stack has left LDS -- with
+// the control flow of the inner-node half written as lane masks instead of divergent branches.  Scalar issue is
+// the dearest resource of this kernel (one instruction per cycle per CU, shared by 32 waves: 32 extra scalar
+// instructions per trip cost 17 % of the launch, profiles/r02_experiments.txt), and hipcc spends ~70 of them per
+// trip on exec bookkeeping for `if (inner) {...} if (both hit) {push} if (none hit) {pop}`.  Here the box
+// arithmetic runs for ALL lanes (a vector instruction costs the same whatever its exec mask; lanes that do not
+// stand at an inner node compute on stale registers and are masked out of the results), the hit tests write
+// lane masks, and descend / push / pop are four exec-masked instructions in one asm block.
+template <bool TOP, bool OCL>
+__device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t stack_base, const float4* s_top,
+                                      uint32_t top_pairs, bool leaf_trip, unsigned long long m_act)
+{
+    const uint32_t cur = L.cur;
+    const uint32_t idx = cur & REF_FIRST_MASK;
+    v4f w0, w1, w2, w3;
+    uint32_t spec_top = REF_DONE;
+    const uint32_t sa = stack_base + ((uint32_t)L.sp << 10);
+    const unsigned long long m_in = __builtin_amdgcn_ballot_w64(cur < REF_LEAF_BIT);
+    const unsigned long long m_leaf = leaf_trip ? (m_act & ~m_in) : 0ull;      // lanes that visit their leaf in this trip
+    {
+        const unsigned long long m_top = TOP ? __builtin_amdgcn_ballot_w64(cur < top_pairs) : 0ull;
+        const unsigned long long m_go = m_in | m_leaf;
+        const unsigned long long m_glob = m_go & ~m_top;
+        const uint32_t a0 = (uint32_t)(uintptr_t)s_top + cur * TOP6_STRIDE;
+        const uint32_t roff = cur << 6;
+        unsigned long long save;
+        // the stack top is read by every lane: entry -1 of a lane's LDS stack is a row that always holds REF_DONE
+        asm volatile("ds_read_b32 %[st], %[sa]\n\t"
+                     "s_mov_b64 %[save], exec\n\t"
+                     "s_mov_b64 exec, %[mtop]\n\t"
+                     "ds_read_b128 %[w0], %[a0]\n\t"
+                     "ds_read_b128 %[w1], %[a0] offset:16\n\t"
+                     "ds_read_b128 %[w2], %[a0] offset:32\n\t"
+                     "ds_read_b128 %[w3], %[a0] offset:48\n\t"
+                     "s_mov_b64 exec, %[mglob]\n\t"
+                     "global_load_dwordx4 %[w0], %[ro], %[rb]\n\t"
+                     "global_load_dwordx4 %[w1], %[ro], %[rb] offset:16\n\t"
+                     "global_load_dwordx4 %[w2], %[ro], %[rb] offset:32\n\t"
+                     "global_load_dwordx4 %[w3], %[ro], %[rb] offset:48\n\t"
+                     "s_mov_b64 exec, %[save]\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [st] "=&v"(spec_top),
+                       [save] "=&s"(save)
+                     : [a0] "v"(a0), [sa] "v"(sa), [ro] "v"(roff), [rb] "s"(p.recs), [mtop] "s"(m_top), [mglob] "s"(m_glob)
+                     : "memory");
+    }
+    if (cur >= REF_LEAF_BIT && cur != REF_DONE && leaf_trip) {       // extend.cl:48-55
+        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
+        const uint32_t first = idx - (uint32_t)p.npairs;
+        if (count == 15u) count = p.scene.leaf_count[first];
+        float dist = L.po.y;
+        tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+                  make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
+                  make_float4(w2.x, w2.y, w2.z, w2.w), false);
+        for (uint32_t i = 1; i < count; ++i) {
+            const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
+            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], false);
+        }
+        L.po.y = dist;
+    }
+    if (m_in != 0) {            // wave-uniform: a trip with no lane at an inner node skips the box arithmetic
+        v2f x0 = __builtin_shufflevector(w0, w0, 0, 1), z0 = __builtin_shufflevector(w0, w0, 2, 3);
+        v2f x1 = __builtin_shufflevector(w1, w1, 0, 1), z1 = __builtin_shufflevector(w1, w1, 2, 3);
+        v2f y0 = __builtin_shufflevector(w2, w2, 0, 1), y1 = __builtin_shufflevector(w2, w2, 2, 3);
+        slabs6(x0, y0, z0, L.px, L.py, L.pz, L.po);
+        slabs6(x1, y1, z1, L.px, L.py, L.pz, L.po);
+        float n0, f0, n1, f1;
+        box2_fast(x0, y0, z0, x1, y1, z1, n0, f0, n1, f1);
+        // extend.cl:36-38,56-76: hit = tmax >= tmin && tmin < dist && tmax > 0 per child; child 1 first iff it is hit
+        // and child 0 is missed or farther; both hit: the farther one is pushed; none hit (or a leaf visited): pop
+        unsigned long long h0, h1, t, save;
+        asm volatile("v_cmp_ge_f32 vcc, %[f0], %[n0]\n\t"
+                     "v_cmp_lt_f32 %[h0], %[n0], %[dist]\n\t"
+                     "s_and_b64 %[h0], %[h0], vcc\n\t"
+                     "v_cmp_lt_f32 vcc, 0, %[f0]\n\t"
+                     "s_and_b64 %[h0], %[h0], vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %[f1], %[n1]\n\t"
+                     "v_cmp_lt_f32 %[h1], %[n1], %[dist]\n\t"
+                     "s_and_b64 %[h1], %[h1], vcc\n\t"
+                     "v_cmp_lt_f32 vcc, 0, %[f1]\n\t"
+                     "s_and_b64 %[h1], %[h1], vcc\n\t"
+                     "s_and_b64 %[h0], %[h0], %[min]\n\t"
+                     "s_and_b64 %[h1], %[h1], %[min]\n\t"
+                     "v_cmp_gt_f32 vcc, %[n0], %[n1]\n\t"
+                     "s_orn2_b64 %[t], vcc, %[h0]\n\t"
+                     "s_and_b64 %[t], %[t], %[h1]\n\t"                 // t = child 1 first
+                     "v_cndmask_b32 %[n0], %[r0], %[r1], %[t]\n\t"      // n0 := the nearer child's reference
+                     "v_cndmask_b32 %[n1], %[r1], %[r0], %[t]\n\t"      // n1 := the farther child's
+                     "s_mov_b64 %[save], exec\n\t"
+                     "s_and_b64 exec, %[h0], %[h1]\n\t"                 // both hit: push the farther, sp + 1
+                     "ds_write_b32 %[sa], %[n1] offset:1024\n\t"
+                     "v_add_u32 %[sp], 1, %[sp]\n\t"
+                     "s_or_b64 %[t], %[h0], %[h1]\n\t"
+                     "s_mov_b64 exec, %[t]\n\t"                         // any hit: descend
+                     "v_mov_b32 %[cur], %[n0]\n\t"
+                     "s_andn2_b64 %[t], %[min], %[t]\n\t"
+                     "s_or_b64 exec, %[t], %[mleaf]\n\t"                // none hit, or a leaf was visited: pop
+                     "v_mov_b32 %[cur], %[st]\n\t"
+                     "v_sub_u32 %[sp], %[sp], 1 clamp\n\t"
+                     "s_mov_b64 exec, %[save]"
+                     : [n0] "+v"(n0), [n1] "+v"(n1), [cur] "+v"(L.cur), [sp] "+v"(L.sp), [h0] "=&s"(h0), [h1] "=&s"(h1), [t] "=&s"(t),
+                       [save] "=&s"(save)
+                     : [f0] "v"(f0), [f1] "v"(f1), [dist] "v"(L.po.y), [r0] "v"(w3.x), [r1] "v"(w3.y), [sa] "v"(sa), [st] "v"(spec_top),
+                       [min] "s"(m_in), [mleaf] "s"(m_leaf)
+                     : "vcc", "memory");
+    } else {
+        // only leaves were visited: pop them
+        unsigned long long save;
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     "s_mov_b64 exec, %[mleaf]\n\t"
+                     "v_mov_b32 %[cur], %[st]\n\t"
+                     "v_sub_u32 %[sp], %[sp], 1 clamp\n\t"
+                     "s_mov_b64 exec, %[save]"
+                     : [cur] "+v"(L.cur), [sp] "+v"(L.sp), [save] "=&s"(save)
+                     : [st] "v"(spec_top), [mleaf] "s"(m_leaf));
+    }
+}
+
 template <int LEAFP, bool RECORD, bool TOP, bool OCL>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
-    __shared__ uint32_t s_stack[PS6][256];                          // 8 KB
+    __shared__ uint32_t s_stack[PS6 + 1][256];                      // 9 KB: row 0 always holds REF_DONE ("entry -1"), the stack proper follows
     __shared__ float4 s_top[TOP ? (TOP6_MAX + 1) * 5 : 4];          // 10 KB
     const uint32_t top_pairs = TOP ? (p.top_pairs < TOP6_MAX ? p.top_pairs : TOP6_MAX) : 0u;
     if (TOP) {
@@ -151,8 +269,9 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
         }
         __syncthreads();
     }
+    s_stack[0][threadIdx.x] = REF_DONE;                               // what a pop from an empty stack yields
     // LDS byte address of this lane's stack entry -1 (entry e at + 1024 (e + 1))
-    const uint32_t stack_base = (uint32_t)(uintptr_t)&s_stack[0][threadIdx.x] - 1024u;
+    const uint32_t stack_base = (uint32_t)(uintptr_t)&s_stack[0][threadIdx.x];
     Lane6 L;
     L.px = L.py = L.pz = (v2f){1.f, 1.f};
     L.po = (v2f){0.f, 1e30f};      // dist == 1e30f <=> nothing to deposit
@@ -234,7 +353,13 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __builtin_amdgcn_ballot_w64(L.cur < REF_LEAF_BIT) == 0;
             ++trip;
         }
-        step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0, act);
+        // the common case in its lane-mask form; a trip with a lane that needs IEEE divisions or whose stack has
+        // left LDS takes the general step
+        const unsigned long long m_deep = __builtin_amdgcn_ballot_w64(L.sp >= PS6);
+        if (((special_mask & act) | m_deep) != 0)
+            step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0, act);
+        else
+            step7<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, act);
     }
     // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
     if (RECORD && live && p.hits) {

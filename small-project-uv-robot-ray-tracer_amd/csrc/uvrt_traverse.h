@@ -53,6 +53,33 @@ __device__ __forceinline__ bool box_fast(v2f tx, v2f ty, v2f tz, float dist, flo
     return (tmax >= tmin) & (tmin < dist) & (tmax > 0);
 }
 
+// extend.cl:29-38 for BOTH child boxes in one block (no hazard padding between statements): entry and exit
+// distances from the (t at min, t at max) pairs.  No operand is NaN on this path.
+__device__ __forceinline__ void box2_fast(v2f tx0, v2f ty0, v2f tz0, v2f tx1, v2f ty1, v2f tz1, float& tmin0, float& tmax0,
+                                          float& tmin1, float& tmax1)
+{
+    float a, b, c;
+    asm("v_min_f32 %[a], %[x0l], %[x0h]\n\t"
+        "v_min_f32 %[b], %[y0l], %[y0h]\n\t"
+        "v_min_f32 %[c], %[z0l], %[z0h]\n\t"
+        "v_max3_f32 %[n0], %[a], %[b], %[c]\n\t"
+        "v_max_f32 %[a], %[x0l], %[x0h]\n\t"
+        "v_max_f32 %[b], %[y0l], %[y0h]\n\t"
+        "v_max_f32 %[c], %[z0l], %[z0h]\n\t"
+        "v_min3_f32 %[f0], %[a], %[b], %[c]\n\t"
+        "v_min_f32 %[a], %[x1l], %[x1h]\n\t"
+        "v_min_f32 %[b], %[y1l], %[y1h]\n\t"
+        "v_min_f32 %[c], %[z1l], %[z1h]\n\t"
+        "v_max3_f32 %[n1], %[a], %[b], %[c]\n\t"
+        "v_max_f32 %[a], %[x1l], %[x1h]\n\t"
+        "v_max_f32 %[b], %[y1l], %[y1h]\n\t"
+        "v_max_f32 %[c], %[z1l], %[z1h]\n\t"
+        "v_min3_f32 %[f1], %[a], %[b], %[c]"
+        : [n0] "=&v"(tmin0), [f0] "=&v"(tmax0), [n1] "=&v"(tmin1), [f1] "=&v"(tmax1), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c)
+        : [x0l] "v"(tx0.x), [x0h] "v"(tx0.y), [y0l] "v"(ty0.x), [y0h] "v"(ty0.y), [z0l] "v"(tz0.x), [z0h] "v"(tz0.y),
+          [x1l] "v"(tx1.x), [x1h] "v"(tx1.y), [y1l] "v"(ty1.x), [y1h] "v"(ty1.y), [z1l] "v"(tz1.x), [z1h] "v"(tz1.y));
+}
+
 // the reference's own form: IEEE divisions, OpenCL min/max as selects (NaN operands: 0/0)
 __device__ __forceinline__ bool box_exact(float ax1, float ax2, float ay1, float ay2, float az1, float az2,
                                           float dx, float dy, float dz, float dist, float& tmin_out)
