@@ -138,34 +138,31 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
 }
 
 // The same step for the common case -- no lane needs the IEEE-division form, no lane's stack has left LDS -- with
-// the control flow of the inner-node half written as lane masks instead of divergent branches.  Scalar issue is
-// the dearest resource of this kernel (one instruction per cycle per CU, shared by 32 waves: 32 extra scalar
-// instructions per trip cost 17 % of the launch, profiles/r02_experiments.txt), and hipcc spends ~70 of them per
-// trip on exec bookkeeping for `if (inner) {...} if (both hit) {push} if (none hit) {pop}`.  Here the box
-// arithmetic runs for ALL lanes (a vector instruction costs the same whatever its exec mask; lanes that do not
-// stand at an inner node compute on stale registers and are masked out of the results), the hit tests write
-// lane masks, and descend / push / pop are four exec-masked instructions in one asm block.
+// the control flow written as lane masks instead of divergent branches.  Scalar issue is the dearest resource of
+// this kernel (one instruction per cycle per CU, shared by 32 waves: 32 extra scalar instructions per trip cost
+// 17 % of the launch, profiles/r02_experiments.txt), and hipcc spends ~70 of them per trip on exec bookkeeping
+// for `if (inner) {...} if (both hit) {push} if (none hit) {pop}`.  Here the caller hands over the lane masks of
+// the trip (one vector comparison each), the box arithmetic runs for ALL lanes (a vector instruction costs the
+// same whatever its exec mask; lanes that do not stand at an inner node compute on stale registers and are
+// masked out of the results), the hit tests narrow exec themselves (v_cmpx), and descend / push / pop are
+// exec-masked instructions of one asm block.
+//   m_in: lanes at an inner node, m_leaf: lanes that visit their leaf in this trip, m_top: lanes whose record is
+//   in the LDS cache, full: the exec mask of the loop (all 64 lanes)
 template <bool TOP, bool OCL>
-__device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t stack_base, const float4* s_top,
-                                      uint32_t top_pairs, bool leaf_trip, unsigned long long m_act)
+__device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t stack_base, uint32_t top_base,
+                                      unsigned long long m_in, unsigned long long m_leaf, unsigned long long m_top,
+                                      unsigned long long full)
 {
     const uint32_t cur = L.cur;
-    const uint32_t idx = cur & REF_FIRST_MASK;
     v4f w0, w1, w2, w3;
-    uint32_t spec_top = REF_DONE;
+    uint32_t spec_top;
     const uint32_t sa = stack_base + ((uint32_t)L.sp << 10);
-    const unsigned long long m_in = __builtin_amdgcn_ballot_w64(cur < REF_LEAF_BIT);
-    const unsigned long long m_leaf = leaf_trip ? (m_act & ~m_in) : 0ull;      // lanes that visit their leaf in this trip
     {
-        const unsigned long long m_top = TOP ? __builtin_amdgcn_ballot_w64(cur < top_pairs) : 0ull;
-        const unsigned long long m_go = m_in | m_leaf;
-        const unsigned long long m_glob = m_go & ~m_top;
-        const uint32_t a0 = (uint32_t)(uintptr_t)s_top + cur * TOP6_STRIDE;
+        const unsigned long long m_glob = (m_in | m_leaf) & ~m_top;
+        const uint32_t a0 = __umul24(cur, TOP6_STRIDE) + top_base;      // only used by lanes with cur < 127
         const uint32_t roff = cur << 6;
-        unsigned long long save;
         // the stack top is read by every lane: entry -1 of a lane's LDS stack is a row that always holds REF_DONE
         asm volatile("ds_read_b32 %[st], %[sa]\n\t"
-                     "s_mov_b64 %[save], exec\n\t"
                      "s_mov_b64 exec, %[mtop]\n\t"
                      "ds_read_b128 %[w0], %[a0]\n\t"
                      "ds_read_b128 %[w1], %[a0] offset:16\n\t"
@@ -176,26 +173,29 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
                      "global_load_dwordx4 %[w1], %[ro], %[rb] offset:16\n\t"
                      "global_load_dwordx4 %[w2], %[ro], %[rb] offset:32\n\t"
                      "global_load_dwordx4 %[w3], %[ro], %[rb] offset:48\n\t"
-                     "s_mov_b64 exec, %[save]\n\t"
+                     "s_mov_b64 exec, %[full]\n\t"
                      "s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [st] "=&v"(spec_top),
-                       [save] "=&s"(save)
-                     : [a0] "v"(a0), [sa] "v"(sa), [ro] "v"(roff), [rb] "s"(p.recs), [mtop] "s"(m_top), [mglob] "s"(m_glob)
+                     : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [st] "=&v"(spec_top)
+                     : [a0] "v"(a0), [sa] "v"(sa), [ro] "v"(roff), [rb] "s"(p.recs), [mtop] "s"(m_top), [mglob] "s"(m_glob),
+                       [full] "s"(full)
                      : "memory");
     }
-    if (cur >= REF_LEAF_BIT && cur != REF_DONE && leaf_trip) {       // extend.cl:48-55
-        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
-        const uint32_t first = idx - (uint32_t)p.npairs;
-        if (count == 15u) count = p.scene.leaf_count[first];
-        float dist = L.po.y;
-        tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
-                  make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
-                  make_float4(w2.x, w2.y, w2.z, w2.w), false);
-        for (uint32_t i = 1; i < count; ++i) {
-            const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
-            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], false);
+    if (m_leaf != 0) {                                       // wave-uniform; m_leaf != 0 means: a leaf trip
+        if ((int32_t)cur < -1) {                             // at a leaf (REF_DONE is -1): extend.cl:48-55
+            const uint32_t idx = cur & REF_FIRST_MASK;
+            uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
+            const uint32_t first = idx - (uint32_t)p.npairs;
+            if (count == 15u) count = p.scene.leaf_count[first];
+            float dist = L.po.y;
+            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+                      make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
+                      make_float4(w2.x, w2.y, w2.z, w2.w), false);
+            for (uint32_t i = 1; i < count; ++i) {
+                const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
+                tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], false);
+            }
+            L.po.y = dist;
         }
-        L.po.y = dist;
     }
     if (m_in != 0) {            // wave-uniform: a trip with no lane at an inner node skips the box arithmetic
         v2f x0 = __builtin_shufflevector(w0, w0, 0, 1), z0 = __builtin_shufflevector(w0, w0, 2, 3);
@@ -207,51 +207,41 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         box2_fast(x0, y0, z0, x1, y1, z1, n0, f0, n1, f1);
         // extend.cl:36-38,56-76: hit = tmax >= tmin && tmin < dist && tmax > 0 per child; child 1 first iff it is hit
         // and child 0 is missed or farther; both hit: the farther one is pushed; none hit (or a leaf visited): pop
-        unsigned long long h0, h1, t, save;
-        asm volatile("v_cmp_ge_f32 vcc, %[f0], %[n0]\n\t"
-                     "v_cmp_lt_f32 %[h0], %[n0], %[dist]\n\t"
-                     "s_and_b64 %[h0], %[h0], vcc\n\t"
-                     "v_cmp_lt_f32 vcc, 0, %[f0]\n\t"
-                     "s_and_b64 %[h0], %[h0], vcc\n\t"
-                     "v_cmp_ge_f32 vcc, %[f1], %[n1]\n\t"
-                     "v_cmp_lt_f32 %[h1], %[n1], %[dist]\n\t"
-                     "s_and_b64 %[h1], %[h1], vcc\n\t"
-                     "v_cmp_lt_f32 vcc, 0, %[f1]\n\t"
-                     "s_and_b64 %[h1], %[h1], vcc\n\t"
-                     "s_and_b64 %[h0], %[h0], %[min]\n\t"
-                     "s_and_b64 %[h1], %[h1], %[min]\n\t"
-                     "v_cmp_gt_f32 vcc, %[n0], %[n1]\n\t"
-                     "s_orn2_b64 %[t], vcc, %[h0]\n\t"
-                     "s_and_b64 %[t], %[t], %[h1]\n\t"                 // t = child 1 first
-                     "v_cndmask_b32 %[n0], %[r0], %[r1], %[t]\n\t"      // n0 := the nearer child's reference
-                     "v_cndmask_b32 %[n1], %[r1], %[r0], %[t]\n\t"      // n1 := the farther child's
-                     "s_mov_b64 %[save], exec\n\t"
+        unsigned long long h0, h1, t;
+        asm volatile("s_mov_b64 exec, %[min]\n\t"
+                     "v_cmpx_ge_f32_e64 %[h0], %[f0], %[n0]\n\t"
+                     "v_cmpx_lt_f32_e64 %[h0], %[n0], %[dist]\n\t"
+                     "v_cmpx_gt_f32_e64 %[h0], %[f0], 0\n\t"            // h0 = exec = inner lanes whose child 0 is hit
+                     "s_mov_b64 exec, %[min]\n\t"
+                     "v_cmpx_ge_f32_e64 %[h1], %[f1], %[n1]\n\t"
+                     "v_cmpx_lt_f32_e64 %[h1], %[n1], %[dist]\n\t"
+                     "v_cmpx_gt_f32_e64 %[h1], %[f1], 0\n\t"            // h1 likewise
+                     "v_cmp_gt_f32 vcc, %[n0], %[n1]\n\t"               // (under exec = h1)
+                     "s_andn2_b64 %[t], %[h1], %[h0]\n\t"
+                     "s_or_b64 %[t], %[t], vcc\n\t"                     // t = child 1 first
                      "s_and_b64 exec, %[h0], %[h1]\n\t"                 // both hit: push the farther, sp + 1
+                     "v_cndmask_b32 %[n1], %[r1], %[r0], %[t]\n\t"
                      "ds_write_b32 %[sa], %[n1] offset:1024\n\t"
                      "v_add_u32 %[sp], 1, %[sp]\n\t"
-                     "s_or_b64 %[t], %[h0], %[h1]\n\t"
-                     "s_mov_b64 exec, %[t]\n\t"                         // any hit: descend
-                     "v_mov_b32 %[cur], %[n0]\n\t"
-                     "s_andn2_b64 %[t], %[min], %[t]\n\t"
+                     "s_or_b64 exec, %[h0], %[h1]\n\t"                  // any hit: descend into the nearer
+                     "v_cndmask_b32 %[cur], %[r0], %[r1], %[t]\n\t"
+                     "s_andn2_b64 %[t], %[min], exec\n\t"
                      "s_or_b64 exec, %[t], %[mleaf]\n\t"                // none hit, or a leaf was visited: pop
                      "v_mov_b32 %[cur], %[st]\n\t"
                      "v_sub_u32 %[sp], %[sp], 1 clamp\n\t"
-                     "s_mov_b64 exec, %[save]"
-                     : [n0] "+v"(n0), [n1] "+v"(n1), [cur] "+v"(L.cur), [sp] "+v"(L.sp), [h0] "=&s"(h0), [h1] "=&s"(h1), [t] "=&s"(t),
-                       [save] "=&s"(save)
-                     : [f0] "v"(f0), [f1] "v"(f1), [dist] "v"(L.po.y), [r0] "v"(w3.x), [r1] "v"(w3.y), [sa] "v"(sa), [st] "v"(spec_top),
-                       [min] "s"(m_in), [mleaf] "s"(m_leaf)
+                     "s_mov_b64 exec, %[full]"
+                     : [n1] "+v"(n1), [cur] "+v"(L.cur), [sp] "+v"(L.sp), [h0] "=&s"(h0), [h1] "=&s"(h1), [t] "=&s"(t)
+                     : [n0] "v"(n0), [f0] "v"(f0), [f1] "v"(f1), [dist] "v"(L.po.y), [r0] "v"(w3.x), [r1] "v"(w3.y), [sa] "v"(sa),
+                       [st] "v"(spec_top), [min] "s"(m_in), [mleaf] "s"(m_leaf), [full] "s"(full)
                      : "vcc", "memory");
     } else {
         // only leaves were visited: pop them
-        unsigned long long save;
-        asm volatile("s_mov_b64 %[save], exec\n\t"
-                     "s_mov_b64 exec, %[mleaf]\n\t"
+        asm volatile("s_mov_b64 exec, %[mleaf]\n\t"
                      "v_mov_b32 %[cur], %[st]\n\t"
                      "v_sub_u32 %[sp], %[sp], 1 clamp\n\t"
-                     "s_mov_b64 exec, %[save]"
-                     : [cur] "+v"(L.cur), [sp] "+v"(L.sp), [save] "=&s"(save)
-                     : [st] "v"(spec_top), [mleaf] "s"(m_leaf));
+                     "s_mov_b64 exec, %[full]"
+                     : [cur] "+v"(L.cur), [sp] "+v"(L.sp)
+                     : [st] "v"(spec_top), [mleaf] "s"(m_leaf), [full] "s"(full));
     }
 }
 
@@ -294,72 +284,88 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     const uint32_t chunk_end = p.chunk;
     const uint32_t n32 = (uint32_t)p.n;
     uint32_t trip = 0;
+    unsigned long long km = ~0ull;          // all ones in a trip that visits leaves (every LEAFP-th)
+    unsigned long long full;                // exec of the loop: all 64 lanes (the launch uses full workgroups)
+    asm volatile("s_mov_b64 %0, exec" : "=s"(full));
+    const uint32_t top_base = (uint32_t)(uintptr_t)s_top;
+    // refill when this many lanes are idle; once the wave's sequence is exhausted only the all-idle exit is left
+    int refill_at = p.refill_min < 1 ? 1 : (p.refill_min > 64 ? 64 : p.refill_min);
 
     for (;;) {
         const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(L.cur == REF_DONE);
         const int nidle = __popcll(idle_mask);
-        if (cursor < chunk_end && nidle >= p.refill_min) {
-            bool spec = false;
-            if (L.cur == REF_DONE) {
-                // results of the rays these lanes finished since the last refill (extend.cl:94-98)
-                if (RECORD && live && p.hits) {
-                    const uint32_t li = p.order ? p.order[slot] : slot;
-                    p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
+        if (nidle >= refill_at) {
+            if (cursor < chunk_end) {
+                bool spec = false;
+                if (L.cur == REF_DONE) {
+                    // results of the rays these lanes finished since the last refill (extend.cl:94-98)
+                    if (RECORD && live && p.hits) {
+                        const uint32_t li = p.order ? p.order[slot] : slot;
+                        p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
+                    }
+                    if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);
+                    live = false;
+                    L.po.y = 1e30f;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                    const uint32_t v = cursor + rank;
+                    const uint32_t gb = (v >> 6) * W + wave;                 // global 64-slot batch
+                    const uint32_t my = gb * 64u + (v & 63u);
+                    // plane (= launch of a batched trace) of the batch: gb / plane_batches, exact after one
+                    // correction step (gb < 2^24 is exact in f32, the rounded reciprocal is off by < 1)
+                    uint32_t pl = (uint32_t)((float)gb * plane_inv);
+                    int32_t within = (int32_t)(gb - pl * p.plane_batches);
+                    if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
+                    else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
+                    if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
+                        set_in_place(plane_off, pl * p.plane_stride);
+                        const float4 rec = p.rays[my];
+                        // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
+                        // and never use y)
+                        set_in_place(L.px, rec.x, rcp_exact(rec.x));
+                        set_in_place(L.py, rec.y, rcp_exact(rec.y));
+                        set_in_place(L.pz, rec.z, rcp_exact(rec.z));
+                        set_in_place(L.po, rec.w, 1e30f);       // generate.cl:34-35
+                        set_in_place(L.triID, 0u);
+                        if (RECORD) { slot = my; live = true; }
+                        set_in_place(L.sp, 0);
+                        set_in_place(L.cur, root6);
+                        const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
+                        const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
+                        spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
+                               !(adx <= 1.0f) || !(ady <= 1.0f) || !(adz <= 1.0f) ||
+                               (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0;
+                    }
                 }
-                if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);
-                live = false;
-                L.po.y = 1e30f;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
-                                      __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                const uint32_t v = cursor + rank;
-                const uint32_t gb = (v >> 6) * W + wave;                 // global 64-slot batch
-                const uint32_t my = gb * 64u + (v & 63u);
-                // plane (= launch of a batched trace) of the batch: gb / plane_batches, exact after one
-                // correction step (gb < 2^24 is exact in f32, the rounded reciprocal is off by < 1)
-                uint32_t pl = (uint32_t)((float)gb * plane_inv);
-                int32_t within = (int32_t)(gb - pl * p.plane_batches);
-                if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
-                else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
-                if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
-                    set_in_place(plane_off, pl * p.plane_stride);
-                    const float4 rec = p.rays[my];
-                    // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
-                    // and never use y)
-                    set_in_place(L.px, rec.x, rcp_exact(rec.x));
-                    set_in_place(L.py, rec.y, rcp_exact(rec.y));
-                    set_in_place(L.pz, rec.z, rcp_exact(rec.z));
-                    set_in_place(L.po, rec.w, 1e30f);       // generate.cl:34-35
-                    set_in_place(L.triID, 0u);
-                    if (RECORD) { slot = my; live = true; }
-                    set_in_place(L.sp, 0);
-                    set_in_place(L.cur, root6);
-                    const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
-                    const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
-                    spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
-                           !(adx <= 1.0f) || !(ady <= 1.0f) || !(adz <= 1.0f) ||
-                           (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0;
-                }
+                cursor += (uint32_t)nidle;
+                special_mask = (special_mask & ~idle_mask) | __builtin_amdgcn_ballot_w64(spec);
+                if (cursor >= chunk_end) refill_at = 64;
             }
-            cursor += (uint32_t)nidle;
-            special_mask = (special_mask & ~idle_mask) | __builtin_amdgcn_ballot_w64(spec);
+            if (__builtin_amdgcn_ballot_w64(L.cur != REF_DONE) == 0) {
+                if (cursor >= chunk_end) break;
+                continue;
+            }
         }
-        const unsigned long long act = __builtin_amdgcn_ballot_w64(L.cur != REF_DONE);
-        if (act == 0) {
-            if (cursor >= chunk_end) break;
-            continue;
-        }
-        bool leaf_trip = true;
-        if (LEAFP > 1) {
-            leaf_trip = (trip % (uint32_t)LEAFP) == 0u || __builtin_amdgcn_ballot_w64(L.cur < REF_LEAF_BIT) == 0;
-            ++trip;
-        }
-        // the common case in its lane-mask form; a trip with a lane that needs IEEE divisions or whose stack has
-        // left LDS takes the general step
+        // lane masks of the trip, one vector comparison each: a reference is an inner record index (>= 0 as a signed
+        // number), REF_DONE (-1) or a leaf (< -1)
+        const unsigned long long m_in = __builtin_amdgcn_ballot_w64((int32_t)L.cur >= 0);
+        const unsigned long long m_lf = __builtin_amdgcn_ballot_w64((int32_t)L.cur < -1);
+        const unsigned long long m_top = TOP ? __builtin_amdgcn_ballot_w64(L.cur < top_pairs) : 0ull;
         const unsigned long long m_deep = __builtin_amdgcn_ballot_w64(L.sp >= PS6);
-        if (((special_mask & act) | m_deep) != 0)
-            step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, (special_mask & act) != 0, act);
+        // leaves are visited in every LEAFP-th trip, and in any trip that has no lane at an inner node
+        unsigned long long kme = km;
+        if (LEAFP > 1) {
+            kme = m_in == 0 ? ~0ull : km;
+            if (LEAFP == 2) km = ~km;
+            else { ++trip; if (trip == (uint32_t)LEAFP) trip = 0; km = trip == 0 ? ~0ull : 0ull; }
+        }
+        // the common case in its lane-mask form; a trip with a lane that needs IEEE divisions (the bit of a
+        // finished lane stays set until the next refill: the exact form is right for every lane) or whose stack
+        // has left LDS takes the general step
+        if ((special_mask | m_deep) != 0)
+            step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, kme != 0, (special_mask & (m_in | m_lf)) != 0, m_in | m_lf);
         else
-            step7<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, act);
+            step7<TOP, OCL>(L, p, stack_base, top_base, m_in, m_lf & kme, m_top, full);
     }
     // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
     if (RECORD && live && p.hits) {
