@@ -289,7 +289,7 @@ int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t s
     sc.tri_count = c->T;
     launch_visit_stats(sc, e->hist.as<uint32_t>(), lamp, light_length, seed_prev, seed_next, c->seed_mode,
                        (int32_t)std::min<int64_t>(n, 32768), s);
-    launch_select_hot(e->hist.as<uint32_t>(), e->perm.as<uint32_t>(), c->npairs, 127, s);
+    launch_select_hot(e->hist.as<uint32_t>(), e->perm.as<uint32_t>(), c->npairs, (int32_t)TOP6_MAX, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ready, s));
     *out = e->perm.as<uint32_t>();
@@ -385,7 +385,7 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     HIP_TRY(hipEventCreateWithFlags(&c->ev_mapfence, hipEventDisableTiming));
     if (const char* e = getenv("UVRT_LANES")) { const int v = atoi(e); if (v >= 1 && v <= uvrt_ctx::MAXL) c->nlanes = v; }
     if (const char* e = getenv("UVRT_PIPELINE")) c->pipeline = atoi(e) != 0;   // developer knob
-    int rc = c->error_flag.ensure(sizeof(uint32_t), true, c->stream);
+    int rc = c->error_flag.ensure(256, true, c->stream);      // the flag; a developer build keeps trip statistics behind it
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
     if (!rc) rc = c->ovf_stack.ensure((size_t)OVF_MAX_ENTRIES * sizeof(uint32_t), false, c->stream);
     if (rc) { delete c; return rc; }
@@ -510,7 +510,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         pr.c1min = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.f);
         pr.c1max = make_float4(b.mx[0], b.mx[1], b.mx[2], 0.f);
         pairs.push_back(pr);
-        if (depth[qi] < 7 && top_pairs < 127) top_pairs = (uint32_t)qi + 1;   // level order: a prefix
+        if (depth[qi] < 7 && top_pairs < TOP6_MAX) top_pairs = (uint32_t)qi + 1;   // level order: a prefix
     }
     if (err) return fail(UVRT_ERR_BVH, "uvrt_set_scene: malformed BVH (code %d)", err);
     // The 4-wide collapse (one level): a node takes the children of its inner children.  Numbered breadth-first
@@ -917,10 +917,10 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     static const int per_cu[6] = {8, 4, 6, 2, 16, 7};
     const int gcode = (c->variant / 10) % 10;
     const int code6 = c->variant == 0 ? 1 : c->variant % 10;   // default: LDS top cache, leaf visits every 2nd trip
-    // default grid: 8 workgroups per CU on one stream; 7 when launches are pipelined over several streams -- the
-    // free wave slot per CU lets the small kernels of the neighbouring launch (generate, accumulate, replay) run at
-    // once instead of queueing behind persistent waves (+1-2 %, profiles/r02_experiments.txt); with four launch
-    // lanes 4 per CU
+    // default grid: 8 workgroups per CU on one stream (20 KB of LDS each: eight fit a CU); 7 when launches are
+    // pipelined over several streams -- the free slot per CU lets the first workgroups of the next launch and the
+    // small kernels around it (generate, accumulate, replay) run at once instead of queueing behind persistent waves
+    // (profiles/r02_experiments.txt); with four launch lanes 4 per CU
     const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : c->cur_pipelined ? 7 : 8;
     if (!launch_extend6(p, code6, c->variant == 0 ? per_cu_default : per_cu[gcode < 6 ? gcode : 0], ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
@@ -1026,6 +1026,27 @@ int uvrt_sync(uvrt_ctx* c)
     uint32_t flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, c->error_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+#ifdef UVRT_TRIP_STATS
+    if (getenv("UVRT_TRIP_STATS")) {
+        unsigned long long st[21];
+        HIP_TRY(hipMemcpy(st, (char*)c->error_flag.p + 8, sizeof st, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset((char*)c->error_flag.p + 8, 0, sizeof st));
+        if (st[1]) {
+            const double t = (double)st[1];
+            fprintf(stderr, "trip stats: waves %llu trips %llu (%.1f per wave)  lanes per trip: inner %.2f leaf-visit %.2f leaf-wait %.2f "
+                    "idle %.2f  cached %.2f  leaf trips %.3f  drain trips %.3f  slow trips %.4f (sp>=9 %.4f >=10 %.4f >=11 %.4f >=12 %.4f)  "
+                    "refills/wave %.1f\n",
+                    st[0], st[1], t / (double)st[0], st[2] / t, st[3] / t, st[4] / t, st[5] / t, st[10] / t, st[6] / t, st[7] / t,
+                    st[8] / t, st[11] / t, st[12] / t, st[13] / t, st[14] / t, (double)st[9] / (double)st[0]);
+            const double w = (double)st[0];
+            fprintf(stderr, "trip clocks (s_memtime ticks per wave): life %.0f  record fetch %.0f  leaf tests %.0f  box tests + descend %.0f  "
+                    "refill %.0f  general step %.0f  rest (loop overhead) %.0f;  per trip: fetch %.0f leaf %.0f box %.0f; per refill %.0f; per general step %.0f\n",
+                    st[19] / w, st[15] / w, st[16] / w, st[17] / w, st[18] / w, st[20] / w,
+                    (st[19] - st[15] - st[16] - st[17] - st[18] - st[20]) / w,
+                    st[15] / t, st[16] / t, st[17] / t, (double)st[18] / (double)(st[9] ? st[9] : 1), (double)st[20] / (double)(st[8] ? st[8] : 1));
+        }
+    }
+#endif
     if (flag) {
         HIP_TRY(hipMemsetAsync(c->error_flag.p, 0, 4, c->stream));
         return fail(UVRT_ERR_STACK, "extend: BVH traversal needed more than 32 stack entries (extend.cl:43)");

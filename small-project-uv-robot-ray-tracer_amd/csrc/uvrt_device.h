@@ -127,6 +127,9 @@ __device__ __forceinline__ float4 generate_ray(float lx, float ly, float lz, flo
     return make_float4((float)(x * s), diry, (float)(y * s), origy);      // :31-37
 }
 
+// ---- the traversal kernel's LDS cache (uvrt_extend6.hip) ----
+constexpr uint32_t TOP6_MAX = 127;        // records cached in LDS
+
 // ---- batched tracing (include/uvrt.h uvrt_trace_batch): several launches' rays side by side ----
 constexpr int MAX_BATCH = 64;          // launches per uvrt_trace_batch / uvrt_replay_batch call
 
@@ -193,7 +196,7 @@ struct ExtendParams {
     uint32_t* ovf_stack;     // persistent kernels: [grid threads][MAX_STACK - LDS entries] stack overflow
     uint64_t ovf_capacity;   // entries (uint32) available in ovf_stack; launches that need more are refused
     int32_t num_cus;         // compute units of the device (persistent grids are sized from it)
-    uint32_t top_pairs;      // pair records [0, top_pairs) = the tree levels cached in LDS (<= 127)
+    uint32_t top_pairs;      // pair records [0, top_pairs) = the tree levels cached in LDS (<= TOP6_MAX)
     int32_t force_exact;     // scene or lamp position outside the fast path's proof conditions
     int32_t flavour;         // 0 strict (canonical), 1 "ocl-amd" fused cross/dot in the triangle test
     const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)

@@ -17,7 +17,7 @@
 //    one child in a register pair;
 //  * ONE record array: pair records [0, P) and 64-byte leaf-triangle records [P, P + T) -- a child
 //    reference is its record index, so the fetch address is one shift-add for inner and leaf lanes;
-//  * the first 127 records (7 tree levels, ~40 % of the node visits) are served from LDS;
+//  * the 127 most visited records of the lamp (62-70 % of the node visits) are served from LDS;
 //  * leaf visits only on every LEAFP-th trip (lanes standing at a leaf wait);
 //  * descend / push / pop as selects instead of nested branches.
 //
@@ -151,15 +151,25 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
 template <bool TOP, bool OCL>
 __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t stack_base, uint32_t top_base,
                                       unsigned long long m_in, unsigned long long m_leaf, unsigned long long m_top,
-                                      unsigned long long full)
+                                      unsigned long long full
+#ifdef UVRT_TRIP_STATS
+                                      , uint32_t (&clk)[4]
+#define UVRT_CLK(i, t0) do { const unsigned long long t1_ = __builtin_readcyclecounter(); clk[i] += (uint32_t)(t1_ - t0); t0 = t1_; } while (0)
+#else
+#define UVRT_CLK(i, t0) do { } while (0)
+#endif
+                                      )
 {
     const uint32_t cur = L.cur;
     v4f w0, w1, w2, w3;
     uint32_t spec_top;
+#ifdef UVRT_TRIP_STATS
+    unsigned long long tclk = __builtin_readcyclecounter();
+#endif
     const uint32_t sa = stack_base + ((uint32_t)L.sp << 10);
     {
         const unsigned long long m_glob = (m_in | m_leaf) & ~m_top;
-        const uint32_t a0 = __umul24(cur, TOP6_STRIDE) + top_base;      // only used by lanes with cur < 127
+        const uint32_t a0 = __umul24(cur, TOP6_STRIDE) + top_base;      // only used by lanes in m_top
         const uint32_t roff = cur << 6;
         // the stack top is read by every lane: entry -1 of a lane's LDS stack is a row that always holds REF_DONE
         asm volatile("ds_read_b32 %[st], %[sa]\n\t"
@@ -180,6 +190,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
                        [full] "s"(full)
                      : "memory");
     }
+    UVRT_CLK(0, tclk);
     if (m_leaf != 0) {                                       // wave-uniform; m_leaf != 0 means: a leaf trip
         if ((int32_t)cur < -1) {                             // at a leaf (REF_DONE is -1): extend.cl:48-55
             const uint32_t idx = cur & REF_FIRST_MASK;
@@ -197,6 +208,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
             L.po.y = dist;
         }
     }
+    UVRT_CLK(1, tclk);
     if (m_in != 0) {            // wave-uniform: a trip with no lane at an inner node skips the box arithmetic
         v2f x0 = __builtin_shufflevector(w0, w0, 0, 1), z0 = __builtin_shufflevector(w0, w0, 2, 3);
         v2f x1 = __builtin_shufflevector(w1, w1, 0, 1), z1 = __builtin_shufflevector(w1, w1, 2, 3);
@@ -243,6 +255,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
                      : [cur] "+v"(L.cur), [sp] "+v"(L.sp)
                      : [st] "v"(spec_top), [mleaf] "s"(m_leaf), [full] "s"(full));
     }
+    UVRT_CLK(2, tclk);
 }
 
 template <int LEAFP, bool RECORD, bool TOP, bool OCL>
@@ -290,11 +303,21 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     const uint32_t top_base = (uint32_t)(uintptr_t)s_top;
     // refill when this many lanes are idle; once the wave's sequence is exhausted only the all-idle exit is left
     int refill_at = p.refill_min < 1 ? 1 : (p.refill_min > 64 ? 64 : p.refill_min);
+#ifdef UVRT_TRIP_STATS     // developer build (tests/tools/trip_stats.sh): where the trips' lanes go
+    uint32_t st_trips = 0, st_in = 0, st_leaf = 0, st_wait = 0, st_idle = 0, st_leaftrips = 0, st_drain = 0, st_slow = 0,
+             st_refills = 0, st_top = 0, st_d9 = 0, st_d10 = 0, st_d11 = 0, st_d12 = 0;
+    uint32_t clk4 = 0;                // cycles in the general step
+    uint32_t clk[4] = {0, 0, 0, 0};   // cycles in: record fetch (issue to data), leaf tests, box tests + descend, refill
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
         const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(L.cur == REF_DONE);
         const int nidle = __popcll(idle_mask);
         if (nidle >= refill_at) {
+#ifdef UVRT_TRIP_STATS
+            unsigned long long tclk = __builtin_readcyclecounter();
+#endif
             if (cursor < chunk_end) {
                 bool spec = false;
                 if (L.cur == REF_DONE) {
@@ -340,6 +363,10 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                 cursor += (uint32_t)nidle;
                 special_mask = (special_mask & ~idle_mask) | __builtin_amdgcn_ballot_w64(spec);
                 if (cursor >= chunk_end) refill_at = 64;
+#ifdef UVRT_TRIP_STATS
+                ++st_refills;
+                { const unsigned long long t1_ = __builtin_readcyclecounter(); clk[3] += (uint32_t)(t1_ - tclk); }
+#endif
             }
             if (__builtin_amdgcn_ballot_w64(L.cur != REF_DONE) == 0) {
                 if (cursor >= chunk_end) break;
@@ -362,11 +389,42 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
         // the common case in its lane-mask form; a trip with a lane that needs IEEE divisions (the bit of a
         // finished lane stays set until the next refill: the exact form is right for every lane) or whose stack
         // has left LDS takes the general step
-        if ((special_mask | m_deep) != 0)
+#ifdef UVRT_TRIP_STATS
+        ++st_trips;
+#if UVRT_TRIP_STATS >= 2
+        st_in += __popcll(m_in); st_leaf += __popcll(m_lf & kme); st_wait += __popcll(m_lf & ~kme);
+        st_idle += 64 - __popcll(m_in | m_lf); st_leaftrips += (m_lf & kme) != 0; st_drain += refill_at == 64 && cursor >= chunk_end;
+        st_top += __popcll(m_top);
+        st_d9 += __builtin_amdgcn_ballot_w64(L.sp >= 9) != 0; st_d10 += __builtin_amdgcn_ballot_w64(L.sp >= 10) != 0;
+        st_d11 += __builtin_amdgcn_ballot_w64(L.sp >= 11) != 0; st_d12 += __builtin_amdgcn_ballot_w64(L.sp >= 12) != 0;
+#endif
+#endif
+        if ((special_mask | m_deep) != 0) {
+#ifdef UVRT_TRIP_STATS
+            const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
             step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, kme != 0, (special_mask & (m_in | m_lf)) != 0, m_in | m_lf);
-        else
+#ifdef UVRT_TRIP_STATS
+            clk4 += (uint32_t)(__builtin_readcyclecounter() - t0_);
+            ++st_slow;
+#endif
+        } else
+#ifdef UVRT_TRIP_STATS
+            step7<TOP, OCL>(L, p, stack_base, top_base, m_in, m_lf & kme, m_top, full, clk);
+#else
             step7<TOP, OCL>(L, p, stack_base, top_base, m_in, m_lf & kme, m_top, full);
+#endif
     }
+#ifdef UVRT_TRIP_STATS
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* st = (unsigned long long*)(p.error_flag + 2);
+        const uint32_t v[20] = {st_trips, st_in, st_leaf, st_wait, st_idle, st_leaftrips, st_drain, st_slow, st_refills, st_top,
+                                st_d9, st_d10, st_d11, st_d12, clk[0], clk[1], clk[2], clk[3],
+                                (uint32_t)(__builtin_readcyclecounter() - t_begin), clk4};
+        for (int i = 0; i < 20; ++i) atomicAdd(&st[i + 1], (unsigned long long)v[i]);
+        atomicAdd(&st[0], 1ull);
+    }
+#endif
     // the wave's sequence is exhausted and every lane is idle: deposit what is still pending
     if (RECORD && live && p.hits) {
         const uint32_t li = p.order ? p.order[slot] : slot;

@@ -10,8 +10,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int MAXS6 = 32;                 // extend.cl:43
-constexpr int PS6 = 8;                    // LDS stack entries per lane
-constexpr uint32_t TOP6_MAX = 127;        // records cached in LDS
+constexpr int PS6 = 8;                    // LDS stack entries per lane.  7.5 % of the trips of the test room see a deeper
+                                          // stack and take the general step (1.6 % with 9 rows, 0.35 % with 10:
+                                          // tests/tools/trip_stats.sh), but more rows gain nothing: 9 rows with 123 cached
+                                          // records (still eight workgroups per CU) measure the same, 10 rows lose 5 % --
+                                          // launch pipelining lives on the eighth workgroup slot of a CU
 constexpr uint32_t TOP6_STRIDE = 80;      // bytes per cached record (64 + 16 padding): 10 KB
 
 // The six slab distances of one child box (extend.cl:31-37), correctly rounded:
