@@ -221,6 +221,7 @@ struct ExtendParams {
     uint32_t plane_batches;
     uint32_t plane_n;
     uint32_t plane_stride;
+    float plane_inv;         // 1 / plane_batches (set by the launch wrapper): first guess of a batch's plane
     // the 4-wide form (uvrt_extend4.hip): per-launch records [2 * nquads units of 64 B] + leaf records
     const void* recs4;
     int32_t nquads;

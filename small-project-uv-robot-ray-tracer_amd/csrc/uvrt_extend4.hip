@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 6) void k_extend4(ExtendParams p)
     unsigned long long special_mask = 0;
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
     uint32_t plane_off = 0;
-    const float plane_inv = 1.0f / (float)p.plane_batches;
+    const float plane_inv = p.plane_inv;
     const uint32_t wave = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t W = gridDim.x * 4u;
     uint32_t cursor = 0;
@@ -259,6 +259,7 @@ bool launch_extend4(const ExtendParams& p0, int grid_per_cu, hipStream_t s)
         p.plane_n = (uint32_t)p.n;
         p.plane_stride = 0;
     }
+    p.plane_inv = 1.0f / (float)p.plane_batches;
     const unsigned need = (unsigned)((p.n + 255) / 256);
     if (need < grid) grid = need;
     const uint64_t waves = (uint64_t)grid * 4;

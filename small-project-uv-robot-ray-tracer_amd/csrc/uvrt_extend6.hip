@@ -84,21 +84,6 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
                      : "memory");
     }
     bool need_pop = is_leaf;
-    if (is_leaf) {                                         // extend.cl:48-55 (before the inner-node block:
-                                                           // the old reference is dead once that block assigns the new one)
-        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
-        const uint32_t first = idx - (uint32_t)p.npairs;
-        if (count == 15u) count = p.scene.leaf_count[first];
-        float dist = L.po.y;
-        tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
-             make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
-             make_float4(w2.x, w2.y, w2.z, w2.w), exact);
-        for (uint32_t i = 1; i < count; ++i) {
-            const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
-            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
-        }
-        L.po.y = dist;
-    }
     if (is_inner) {
         float d0, d1;
         bool h0, h1;
@@ -128,6 +113,22 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         }
         need_pop = !(h0 | h1);
         L.cur = nearer;
+    }
+    // extend.cl:48-55 -- AFTER the inner-node block (other lanes): the triangles of a leaf with several of them
+    // are fetched when the node records' registers are free again
+    if (is_leaf) {
+        uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
+        const uint32_t first = idx - (uint32_t)p.npairs;
+        if (count == 15u) count = p.scene.leaf_count[first];
+        float dist = L.po.y;
+        tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+             make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
+             make_float4(w2.x, w2.y, w2.z, w2.w), exact);
+        for (uint32_t i = 1; i < count; ++i) {
+            const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
+            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
+        }
+        L.po.y = dist;
     }
     if (need_pop) {
         uint32_t popped = spec_top;                        // REF_DONE when the stack is empty
@@ -258,6 +259,224 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
     UVRT_CLK(2, tclk);
 }
 
+// ---- the common trips as ONE hand-written instruction stream ------------------------------------------------
+// run7 executes common trips (what step7 does for one) back to back until something else has to happen and says
+// what: 1 = refill (at most `active_min` lanes hold a ray), 2 = a trip for the general step (a lane needs the
+// IEEE-division form or its stack has left LDS, or a leaf of this trip holds more than one triangle).  hipcc's
+// code for the same loop spends ~43 scalar and ~75 vector instructions on an inner-node trip, a third of them
+// exec / phi bookkeeping between the trip's masks and its record fetch; this stream has 31 and 57, and the
+// chain from a trip's descend to the next trip's fetch is 8 vector + 14 scalar instructions.
+//
+// Registers: the lane state are asm operands; everything else lives in v40-v63 (declared clobbered), five scalar
+// pairs m0-m4 and the 32-bit %[code].
+//   W0-W3 = v[40:43] v[44:47] v[48:51] v[52:55]   the fetched record (inner: child 0 x,z | child 1 x,z | y | refs)
+//   ST v56 (stack top), SA v57 (its address); the record's LDS / memory address sits in v52 / v53 until the last
+//   quarter of the record lands there; v[58:63] slab temporaries, then box distances (+ v54).  Leaf lanes (exec =
+//   m3) use v47, v51-v55 and v57-v63 for the triangle test: the other lanes' copies of those registers are untouched
+//   m0 = inner lanes; m1 = lanes at a leaf, later "child 1 hit"; m2 = lanes with a cached record, later "child 0
+//   hit" (and the v_cmpx results of the triangle test); m3 = lanes visiting their leaf; m4 = scratch masks;
+//   %[code] = scratch (lane count, leaf-trip flag) until it carries the exit code
+// Arithmetic: slabs / boxes / hit tests are step7's (slabs6, box2_fast, the v_cmpx tail); the triangle test is
+// tri6<OCL> instruction for instruction (extend.cl:6-27), early returns as v_cmpx narrowing of exec.
+// A kernel with this stream must not spill: scratch use costs the launch pipelining 14 % (measured); the general
+// step is ordered (inner block before leaf block) so that hipcc's allocation fits in the 64 registers.
+#define R7_CROSS_STRICT(dst, ay, bz, az, by) \
+    "v_mul_f32 v58, " ay ", " bz "\n\t" "v_mul_f32 v59, " az ", " by "\n\t" "v_sub_f32 " dst ", v58, v59\n\t"
+#define R7_CROSS_OCL(dst, ay, bz, az, by) \
+    "v_mul_f32 v59, " az ", " by "\n\t" "v_fma_f32 " dst ", " ay ", " bz ", -v59\n\t"
+// dot(a, b): strict = (ax*bx + ay*by) + az*bz in source order; ocl = fma(az, bz, fma(ay, by, ax*bx))
+#define R7_DOT_STRICT(dst, ax, ay, az, bx, by, bz) \
+    "v_mul_f32 v58, " ax ", " bx "\n\t" "v_mul_f32 v59, " ay ", " by "\n\t" "v_add_f32 v58, v58, v59\n\t" \
+    "v_mul_f32 v59, " az ", " bz "\n\t" "v_add_f32 " dst ", v58, v59\n\t"
+#define R7_DOT_OCL(dst, ax, ay, az, bx, by, bz) \
+    "v_mul_f32 v58, " ax ", " bx "\n\t" "v_fma_f32 v58, " ay ", " by ", v58\n\t" "v_fma_f32 " dst ", " az ", " bz ", v58\n\t"
+#define R7_TRI(CROSS, DOT)                                                                                          \
+    /* h = cross(dir, e2) -> v52 v53 v54 */                                                                         \
+    CROSS("v52", "%[dy]", "v50", "%[dz]", "v49")                                                                    \
+    CROSS("v53", "%[dz]", "v48", "%[dx]", "v50")                                                                    \
+    CROSS("v54", "%[dx]", "v49", "%[dy]", "v48")                                                                    \
+    DOT("v55", "v44", "v45", "v46", "v52", "v53", "v54")                    /* a = dot(e1, h) */                    \
+    "v_and_b32 v58, 0x7fffffff, v55\n\t"                                                                                 \
+    "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v58\n\t"                            /* if (fabs(a) < 1e-5f) return */       \
+    "v_rcp_f32 v60, v55\n\t"                                                                                        \
+    "v_sub_f32 v61, %[ox], v40\n\t"                                         /* s = orig - v0 */                     \
+    "v_sub_f32 v62, %[oy], v41\n\t"                                                                                 \
+    "v_sub_f32 v63, %[oz], v42\n\t"                                                                                 \
+    "v_fma_f32 v57, -v55, v60, 1.0\n\t"                                     /* f = RN(1 / a): rcp + one Newton step */ \
+    "v_fma_f32 v60, v57, v60, v60\n\t"                                                                              \
+    DOT("v51", "v61", "v62", "v63", "v52", "v53", "v54")                                                            \
+    "v_mul_f32 v51, v60, v51\n\t"                                           /* u = f * dot(s, h) */                 \
+    "v_cmpx_nlt_f32_e64 %[m2], v51, 0\n\t"                               /* if (u < 0 || u > 1) return */        \
+    "v_cmpx_ngt_f32_e64 %[m2], v51, 1.0\n\t"                                                                     \
+    CROSS("v52", "v62", "v46", "v63", "v45")                                /* q = cross(s, e1) */                  \
+    CROSS("v53", "v63", "v44", "v61", "v46")                                                                        \
+    CROSS("v54", "v61", "v45", "v62", "v44")                                                                        \
+    DOT("v47", "%[dx]", "%[dy]", "%[dz]", "v52", "v53", "v54")                                                      \
+    "v_mul_f32 v47, v60, v47\n\t"                                           /* v = f * dot(dir, q) */               \
+    "v_cmpx_nlt_f32_e64 %[m2], v47, 0\n\t"                               /* if (v < 0 || u + v > 1) return */    \
+    "v_add_f32 v55, v51, v47\n\t"                                                                                   \
+    "v_cmpx_ngt_f32_e64 %[m2], v55, 1.0\n\t"                                                                     \
+    DOT("v55", "v48", "v49", "v50", "v52", "v53", "v54")                                                            \
+    "v_mul_f32 v55, v60, v55\n\t"                                           /* t = f * dot(e2, q) */                \
+    "v_cmpx_lt_f32_e32 vcc, 0x38d1b717, v55\n\t"                             /* if (t > 1e-4f && t < dist) */        \
+    "v_cmpx_lt_f32_e64 %[m2], v55, %[dist]\n\t"                                                                  \
+    "v_mov_b32 %[dist], v55\n\t"                                                                                    \
+    "v_mov_b32 %[tri], v43\n\t"
+
+#define R7_CLOBBERS "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+#define R7_BODY(TRI) \
+        "1:\n\t" \
+        "v_cmp_lt_i32_e64 %[m0], -1, %[cur]\n\t" \
+        "v_cmp_gt_i32_e64 %[m1], -1, %[cur]\n\t" \
+        "v_cmp_lt_u32_e64 vcc, 7, %[sp]\n\t" \
+        "s_or_b64 %[m4], %[m0], %[m1]\n\t" \
+        "s_bcnt1_i32_b64 %[code], %[m4]\n\t" \
+        "s_cmp_le_u32 %[code], %[amin]\n\t" \
+        "s_cbranch_scc1 7f\n\t" \
+        "s_or_b64 %[m4], vcc, %[spec]\n\t" \
+        "s_cbranch_scc1 8f\n\t" \
+        "v_cmp_gt_u32_e64 %[m2], %[tp], %[cur]\n\t" \
+        "s_cmp_eq_u64 %[m0], 0\n\t" \
+        "s_cselect_b32 %[code], -1, %[km]\n\t" \
+        "s_cmp_lg_u32 %[code], 0\n\t" \
+        "s_cselect_b64 %[m3], %[m1], 0\n\t" \
+        "s_cmp_lg_u64 %[m3], 0\n\t" \
+        "s_cbranch_scc0 3f\n\t" \
+        "s_mov_b64 exec, %[m3]\n\t" \
+        "v_bfe_u32 v58, %[cur], 27, 4\n\t" \
+        "v_cmp_ne_u32_e64 %[m4], 1, v58\n\t" \
+        "s_mov_b64 exec, %[full]\n\t" \
+        "s_cmp_lg_u64 %[m4], 0\n\t" \
+        "s_cbranch_scc1 8f\n\t" \
+        "3:\n\t" \
+        "s_not_b32 %[km], %[km]\n\t" \
+        "v_lshl_add_u32 v57, %[sp], 10, %[sb]\n\t" \
+        "v_mul_u32_u24 v52, 0x50, %[cur]\n\t" \
+        "v_add_u32 v52, %[tb], v52\n\t" \
+        "v_lshlrev_b32 v53, 6, %[cur]\n\t" \
+        "s_or_b64 %[m4], %[m0], %[m3]\n\t" \
+        "s_andn2_b64 %[m4], %[m4], %[m2]\n\t" \
+        "ds_read_b32 v56, v57\n\t" \
+        "s_mov_b64 exec, %[m2]\n\t" \
+        "ds_read_b128 v[40:43], v52\n\t" \
+        "ds_read_b128 v[44:47], v52 offset:16\n\t" \
+        "ds_read_b128 v[48:51], v52 offset:32\n\t" \
+        "ds_read_b128 v[52:55], v52 offset:48\n\t" \
+        "s_mov_b64 exec, %[m4]\n\t" \
+        "global_load_dwordx4 v[40:43], v53, %[rb]\n\t" \
+        "global_load_dwordx4 v[44:47], v53, %[rb] offset:16\n\t" \
+        "global_load_dwordx4 v[48:51], v53, %[rb] offset:32\n\t" \
+        "global_load_dwordx4 v[52:55], v53, %[rb] offset:48\n\t" \
+        "s_mov_b64 exec, %[full]\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "s_cmp_eq_u64 %[m3], 0\n\t" \
+        "s_cbranch_scc1 4f\n\t" \
+        "s_mov_b64 exec, %[m3]\n\t" \
+        TRI \
+        "s_mov_b64 exec, %[full]\n\t" \
+        "4:\n\t" \
+        "s_cmp_eq_u64 %[m0], 0\n\t" \
+        "s_cbranch_scc1 5f\n\t" \
+        "v_pk_add_f32 v[48:49], v[48:49], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 v[58:59], v[40:41], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[60:61], v[42:43], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[62:63], v[48:49], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_fma_f32 v[40:41], %[px], v[58:59], v[40:41] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[42:43], %[pz], v[60:61], v[42:43] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[48:49], %[py], v[62:63], v[48:49] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[40:41], v[40:41], %[px], v[58:59] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[42:43], v[42:43], %[pz], v[60:61] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[48:49], v[48:49], %[py], v[62:63] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_add_f32 v[50:51], v[50:51], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 v[58:59], v[44:45], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[60:61], v[46:47], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[62:63], v[50:51], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_fma_f32 v[44:45], %[px], v[58:59], v[44:45] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[46:47], %[pz], v[60:61], v[46:47] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[50:51], %[py], v[62:63], v[50:51] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[44:45], v[44:45], %[px], v[58:59] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[46:47], v[46:47], %[pz], v[60:61] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[50:51], v[50:51], %[py], v[62:63] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_min_f32 v58, v40, v41\n\t" \
+        "v_min_f32 v59, v48, v49\n\t" \
+        "v_min_f32 v60, v42, v43\n\t" \
+        "v_max3_f32 v61, v58, v59, v60\n\t" \
+        "v_max_f32 v58, v40, v41\n\t" \
+        "v_max_f32 v59, v48, v49\n\t" \
+        "v_max_f32 v60, v42, v43\n\t" \
+        "v_min3_f32 v62, v58, v59, v60\n\t" \
+        "v_min_f32 v58, v44, v45\n\t" \
+        "v_min_f32 v59, v50, v51\n\t" \
+        "v_min_f32 v60, v46, v47\n\t" \
+        "v_max3_f32 v63, v58, v59, v60\n\t" \
+        "v_max_f32 v58, v44, v45\n\t" \
+        "v_max_f32 v59, v50, v51\n\t" \
+        "v_max_f32 v60, v46, v47\n\t" \
+        "v_min3_f32 v54, v58, v59, v60\n\t" \
+        "s_mov_b64 exec, %[m0]\n\t" \
+        "v_cmpx_ge_f32_e64 %[m2], v62, v61\n\t" \
+        "v_cmpx_lt_f32_e64 %[m2], v61, %[dist]\n\t" \
+        "v_cmpx_gt_f32_e64 %[m2], v62, 0\n\t" \
+        "s_mov_b64 exec, %[m0]\n\t" \
+        "v_cmpx_ge_f32_e64 %[m1], v54, v63\n\t" \
+        "v_cmpx_lt_f32_e64 %[m1], v63, %[dist]\n\t" \
+        "v_cmpx_gt_f32_e64 %[m1], v54, 0\n\t" \
+        "v_cmp_gt_f32 vcc, v61, v63\n\t" \
+        "s_andn2_b64 %[m4], %[m1], %[m2]\n\t" \
+        "s_or_b64 %[m4], %[m4], vcc\n\t" \
+        "s_and_b64 exec, %[m2], %[m1]\n\t" \
+        "v_cndmask_b32 v63, v53, v52, %[m4]\n\t" \
+        "ds_write_b32 v57, v63 offset:1024\n\t" \
+        "v_add_u32 %[sp], 1, %[sp]\n\t" \
+        "s_or_b64 exec, %[m2], %[m1]\n\t" \
+        "v_cndmask_b32 %[cur], v52, v53, %[m4]\n\t" \
+        "s_andn2_b64 %[m4], %[m0], exec\n\t" \
+        "s_or_b64 exec, %[m4], %[m3]\n\t" \
+        "v_mov_b32 %[cur], v56\n\t" \
+        "v_sub_u32 %[sp], %[sp], 1 clamp\n\t" \
+        "s_mov_b64 exec, %[full]\n\t" \
+        "s_branch 1b\n\t" \
+        "5:\n\t" \
+        "s_mov_b64 exec, %[m3]\n\t" \
+        "v_mov_b32 %[cur], v56\n\t" \
+        "v_sub_u32 %[sp], %[sp], 1 clamp\n\t" \
+        "s_mov_b64 exec, %[full]\n\t" \
+        "s_branch 1b\n\t" \
+        "7:\n\t" \
+        "s_mov_b32 %[code], 1\n\t" \
+        "s_branch 9f\n\t" \
+        "8:\n\t" \
+        "s_mov_b32 %[code], 2\n\t" \
+        "9:"
+
+#define R7_OPERANDS \
+        : [cur] "+v"(L.cur), [sp] "+v"(L.sp), [dist] "+v"(dist), [tri] "+v"(L.triID), [km] "+s"(km), [code] "=&s"(code), \
+          [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4) \
+        : [px] "v"(L.px), [py] "v"(L.py), [pz] "v"(L.pz), [po] "v"(L.po), [dx] "v"(L.px.x), [dy] "v"(L.py.x), [dz] "v"(L.pz.x), \
+          [oy] "v"(oy), [sb] "v"(stack_base), [tb] "s"(__builtin_amdgcn_readfirstlane(top_base)), [full] "s"(full), [rb] "s"(p.recs), [spec] "s"(special_mask), \
+          [tp] "s"(top_pairs), [amin] "s"(active_min), [ox] "s"(p.ox), [oz] "s"(p.oz) \
+        : "memory", "scc", "vcc", R7_CLOBBERS
+
+template <bool OCL, int LEAFP>
+__device__ __forceinline__ int run7(Lane6& L, const ExtendParams& p, uint32_t stack_base, uint32_t top_base,
+                                    uint32_t top_pairs, unsigned long long special_mask, int& km,
+                                    unsigned long long full, int active_min)
+{
+    static_assert(LEAFP == 2, "run7 visits leaves in every second trip");
+    static_assert(TOP6_STRIDE == 0x50, "run7 multiplies by the literal stride of the LDS cache");
+    int code;
+    unsigned long long m0, m1, m2, m3, m4;   // scalar temporaries of the stream: lane masks
+    // {d, 1/d} per axis, {origin y, dist}: the scalar halves are separate operands (an asm operand has no
+    // sub-register syntax), tied to the same registers as the pairs by construction of Lane6
+    float dist = L.po.y;
+    const float oy = L.po.x;
+    static_assert(PS6 == 8, "run7 compares the stack pointer with the literal PS6 - 1");
+    if constexpr (OCL) asm volatile(R7_BODY(R7_TRI(R7_CROSS_OCL, R7_DOT_OCL)) R7_OPERANDS);
+    else asm volatile(R7_BODY(R7_TRI(R7_CROSS_STRICT, R7_DOT_STRICT)) R7_OPERANDS);
+    L.po.y = dist;
+    return code;
+}
+
 template <int LEAFP, bool RECORD, bool TOP, bool OCL>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
@@ -287,7 +506,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
     const uint32_t root6 = (p.perm && p.root_ref6 < REF_LEAF_BIT) ? p.perm[p.root_ref6] : p.root_ref6;
     uint32_t plane_off = 0;        // ints from my_counts to the plane of the ray this lane holds
-    const float plane_inv = 1.0f / (float)p.plane_batches;
+    const float plane_inv = p.plane_inv;
 
     // wave w traces the 64-ray batches w, w + W, w + 2W, ...: static ownership, no atomics, and batches
     // dealt round-robin so that ordered rays stay load-balanced
@@ -302,7 +521,8 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     asm volatile("s_mov_b64 %0, exec" : "=s"(full));
     const uint32_t top_base = (uint32_t)(uintptr_t)s_top;
     // refill when this many lanes are idle; once the wave's sequence is exhausted only the all-idle exit is left
-    int refill_at = p.refill_min < 1 ? 1 : (p.refill_min > 64 ? 64 : p.refill_min);
+    const int refill_c = p.refill_min;      // 1..64 (launch_extend6)
+    int refill_at = refill_c;
 #ifdef UVRT_TRIP_STATS     // developer build (tests/tools/trip_stats.sh): where the trips' lanes go
     uint32_t st_trips = 0, st_in = 0, st_leaf = 0, st_wait = 0, st_idle = 0, st_leaftrips = 0, st_drain = 0, st_slow = 0,
              st_refills = 0, st_top = 0, st_d9 = 0, st_d10 = 0, st_d11 = 0, st_d12 = 0;
@@ -311,6 +531,85 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
 
+#ifdef UVRT_TRIP_STATS
+    constexpr bool asm_trips = false;       // the statistics live in the C++ form of the loop
+#else
+    constexpr bool asm_trips = TOP && LEAFP == 2;
+#endif
+    if constexpr (asm_trips) {
+        int kflag = -1;                         // -1 in a trip that visits leaves (every second one)
+        for (;;) {
+            // common trips back to back (run7), until lanes want new rays (1) or a trip needs the general step (2)
+            // (scalars that pass through the asm statement are re-declared uniform: hipcc otherwise treats them, and
+            // every loop-carried scalar whose update depends on them, as divergent and keeps them in vector registers)
+            // (two call sites: a select between the two thresholds would drag `cursor` into a vector register)
+            int why;
+            if (cursor < chunk_end) why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 64 - refill_c);
+            else why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 0);
+            why = __builtin_amdgcn_readfirstlane(why);
+            kflag = __builtin_amdgcn_readfirstlane(kflag);
+            if (why == 1) {
+                const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(L.cur == REF_DONE);
+                const int nidle = __popcll(idle_mask);
+                if (cursor < chunk_end) {
+                    bool spec = false;
+                    if (L.cur == REF_DONE) {
+                        // results of the rays these lanes finished since the last refill (extend.cl:94-98)
+                        if (RECORD && live && p.hits) {
+                            const uint32_t li = p.order ? p.order[slot] : slot;
+                            p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
+                        }
+                        if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);
+                        live = false;
+                        L.po.y = 1e30f;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                        const uint32_t v = cursor + rank;
+                        const uint32_t gb = (v >> 6) * W + wave;                 // global 64-slot batch
+                        const uint32_t my = gb * 64u + (v & 63u);
+                        // plane (= launch of a batched trace) of the batch: gb / plane_batches, exact after one
+                        // correction step (gb < 2^24 is exact in f32, the rounded reciprocal is off by < 1)
+                        uint32_t pl = (uint32_t)((float)gb * plane_inv);
+                        int32_t within = (int32_t)(gb - pl * p.plane_batches);
+                        if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
+                        else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
+                        if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
+                            set_in_place(plane_off, pl * p.plane_stride);
+                            const float4 rec = p.rays[my];
+                            // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
+                            // and never use y)
+                            set_in_place(L.px, rec.x, rcp_exact(rec.x));
+                            set_in_place(L.py, rec.y, rcp_exact(rec.y));
+                            set_in_place(L.pz, rec.z, rcp_exact(rec.z));
+                            set_in_place(L.po, rec.w, 1e30f);       // generate.cl:34-35
+                            set_in_place(L.triID, 0u);
+                            if (RECORD) { slot = my; live = true; }
+                            set_in_place(L.sp, 0);
+                            set_in_place(L.cur, root6);
+                            const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
+                            const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
+                            spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
+                                   !(adx <= 1.0f) || !(ady <= 1.0f) || !(adz <= 1.0f) ||
+                                   (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0;
+                        }
+                    }
+                    cursor += (uint32_t)nidle;
+                    special_mask = (special_mask & ~idle_mask) | __builtin_amdgcn_ballot_w64(spec);
+                    if (cursor >= chunk_end) refill_at = 64;
+                }
+                if (cursor >= chunk_end && __builtin_amdgcn_ballot_w64(L.cur != REF_DONE) == 0) break;
+                continue;
+            }
+            const unsigned long long m_in = __builtin_amdgcn_ballot_w64((int32_t)L.cur >= 0);
+            const unsigned long long m_lf = __builtin_amdgcn_ballot_w64((int32_t)L.cur < -1);
+            const bool leaf_trip = m_in == 0 || kflag != 0;
+            kflag = ~kflag;
+            // (two specialisations of the general step -- hipcc's register allocation for the one with both
+            // arithmetic forms does not fit beside the registers run7 reserves)
+            if ((special_mask & (m_in | m_lf)) != 0) step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, true, m_in | m_lf);
+            else step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, false, m_in | m_lf);
+        }
+    } else
     for (;;) {
         const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(L.cur == REF_DONE);
         const int nidle = __popcll(idle_mask);
@@ -488,6 +787,8 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
         p.plane_n = (uint32_t)p.n;
         p.plane_stride = 0;
     }
+    p.plane_inv = 1.0f / (float)p.plane_batches;
+    p.refill_min = p.refill_min < 1 ? 1 : (p.refill_min > 64 ? 64 : p.refill_min);
     const unsigned need = (unsigned)((p.n + 255) / 256);
     if (need < grid) grid = need;
     const uint64_t waves = (uint64_t)grid * 4;
