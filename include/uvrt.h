@@ -193,13 +193,13 @@ int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
  * (extend.cl:25,66-76 make those order-dependent; none in 25 M rays on the test room).  Off by default: the
  * default walk is bit-exact unconditionally.  uvrt_trace_batch always uses the default walk. */
 int uvrt_set_wide_bvh(uvrt_ctx* ctx, int32_t on);
-/* Which node-pair records the traversal serves from LDS: 1 (default) = the 127 records the lamp's photons
+/* Which node-pair records the traversal serves from LDS: 1 (default) = the 175 records the lamp's photons
  * visit most, found on the device from a sample of the launch's own rays the first time a lamp position is
- * seen (62-70 % of all inner-node visits on the test room); 0 = the first 127 in breadth-first order
+ * seen (62-70 % of all inner-node visits on the test room); 0 = the first levels of the tree in breadth-first order
  * (31-40 %).  Only the order of records in memory changes; results never depend on it. */
 int uvrt_set_hot_records(uvrt_ctx* ctx, int32_t mode);
 /* Renumber the node-pair records of the default extend kernel: record i (breadth-first index of the
- * inner node, as uvrt_set_scene lays them out) moves to perm[i]; the first 127 records of the new
+ * inner node, as uvrt_set_scene lays them out) moves to perm[i]; the first 175 records of the new
  * numbering are served from LDS.  Results do not depend on it.  NULL restores the breadth-first
  * order.  Reset by uvrt_set_scene. */
 int uvrt_set_record_perm(uvrt_ctx* ctx, const uint32_t* perm, int32_t n);

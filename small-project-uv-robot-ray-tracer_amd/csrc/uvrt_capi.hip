@@ -510,7 +510,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         pr.c1min = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.f);
         pr.c1max = make_float4(b.mx[0], b.mx[1], b.mx[2], 0.f);
         pairs.push_back(pr);
-        if (depth[qi] < 7 && top_pairs < TOP6_MAX) top_pairs = (uint32_t)qi + 1;   // level order: a prefix
+        if (depth[qi] < 8 && top_pairs < TOP6_MAX) top_pairs = (uint32_t)qi + 1;   // level order: a prefix
     }
     if (err) return fail(UVRT_ERR_BVH, "uvrt_set_scene: malformed BVH (code %d)", err);
     // The 4-wide collapse (one level): a node takes the children of its inner children.  Numbered breadth-first

@@ -128,7 +128,7 @@ __device__ __forceinline__ float4 generate_ray(float lx, float ly, float lz, flo
 }
 
 // ---- the traversal kernel's LDS cache (uvrt_extend6.hip) ----
-constexpr uint32_t TOP6_MAX = 127;        // records cached in LDS
+constexpr uint32_t TOP6_MAX = 175;        // records cached in LDS: 176 x 64 B + 9 stack rows = 20 KB per workgroup, eight per CU
 
 // ---- batched tracing (include/uvrt.h uvrt_trace_batch): several launches' rays side by side ----
 constexpr int MAX_BATCH = 64;          // launches per uvrt_trace_batch / uvrt_replay_batch call

@@ -17,7 +17,7 @@
 //    one child in a register pair;
 //  * ONE record array: pair records [0, P) and 64-byte leaf-triangle records [P, P + T) -- a child
 //    reference is its record index, so the fetch address is one shift-add for inner and leaf lanes;
-//  * the 127 most visited records of the lamp (62-70 % of the node visits) are served from LDS;
+//  * the 175 most visited records of the lamp (two thirds of the node visits) are served from LDS;
 //  * leaf visits only on every LEAFP-th trip (lanes standing at a leaf wait);
 //  * descend / push / pop as selects instead of nested branches.
 //
@@ -55,8 +55,7 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         const unsigned long long m_go = m_in | (leaf_trip ? (m_act & ~m_in) : 0ull);
         const unsigned long long m_glob = m_go & ~m_top;
         const unsigned long long m_stk = m_go & m_sp;
-        // LDS copy of record r at byte 80 r: the 16 padding bytes spread the lanes of a ds_read_b128
-        // over sixteen 4-bank windows (20 r mod 64) instead of four
+        // LDS copy of record r at byte TOP6_STRIDE * r
         const uint32_t a0 = (uint32_t)(uintptr_t)s_top + cur * TOP6_STRIDE;
         // byte offset of the record: the shift drops the leaf flag and count bits of a reference
         // (record indices are < 2^26: uvrt_capi.hip checks P + T), the base address is scalar
@@ -351,7 +350,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "3:\n\t" \
         "s_not_b32 %[km], %[km]\n\t" \
         "v_lshl_add_u32 v57, %[sp], 10, %[sb]\n\t" \
-        "v_mul_u32_u24 v52, 0x50, %[cur]\n\t" \
+        "v_mul_u32_u24 v52, 0x40, %[cur]\n\t" \
         "v_add_u32 v52, %[tb], v52\n\t" \
         "v_lshlrev_b32 v53, 6, %[cur]\n\t" \
         "s_or_b64 %[m4], %[m0], %[m3]\n\t" \
@@ -463,7 +462,7 @@ __device__ __forceinline__ int run7(Lane6& L, const ExtendParams& p, uint32_t st
                                     unsigned long long full, int active_min)
 {
     static_assert(LEAFP == 2, "run7 visits leaves in every second trip");
-    static_assert(TOP6_STRIDE == 0x50, "run7 multiplies by the literal stride of the LDS cache");
+    static_assert(TOP6_STRIDE == 0x40, "run7 multiplies by the literal stride of the LDS cache");
     int code;
     unsigned long long m0, m1, m2, m3, m4;   // scalar temporaries of the stream: lane masks
     // {d, 1/d} per axis, {origin y, dist}: the scalar halves are separate operands (an asm operand has no
@@ -481,13 +480,13 @@ template <int LEAFP, bool RECORD, bool TOP, bool OCL>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
     __shared__ uint32_t s_stack[PS6 + 1][256];                      // 9 KB: row 0 always holds REF_DONE ("entry -1"), the stack proper follows
-    __shared__ float4 s_top[TOP ? (TOP6_MAX + 1) * 5 : 4];          // 10 KB
+    __shared__ float4 s_top[TOP ? (TOP6_MAX + 1) * (TOP6_STRIDE / 16) : 4];          // 11 KB
     const uint32_t top_pairs = TOP ? (p.top_pairs < TOP6_MAX ? p.top_pairs : TOP6_MAX) : 0u;
     if (TOP) {
         const float4* src = (const float4*)p.recs;
         for (uint32_t i = threadIdx.x; i < top_pairs * 4u; i += 256u) {
             const uint32_t rec = i >> 2;
-            s_top[rec * 5u + (i & 3u)] = src[i];
+            s_top[rec * (TOP6_STRIDE / 16u) + (i & 3u)] = src[i];
         }
         __syncthreads();
     }

@@ -2,7 +2,7 @@
 //
 // The traversal kernel (uvrt_extend6.hip) serves the first records of its numbering from LDS.  Which
 // records are hot depends on the lamp: the 127 most visited ones take 62-70 % of all inner-node visits on
-// the test room, the first 127 in breadth-first order 31-40 % (profiles/r02_record_layout_experiment.txt).
+// the test room (the cache holds 175), the first 127 in breadth-first order 31-40 % (profiles/r02_record_layout_experiment.txt).
 // For every new lamp position the context therefore
 //   1. traces a sample of the launch's own photons (global ids [0, S)) with k_visit_stats -- a plain
 //      one-ray-per-lane closest-hit traversal in fast arithmetic that only COUNTS inner-node visits, and

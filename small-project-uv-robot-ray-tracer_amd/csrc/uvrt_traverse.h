@@ -15,7 +15,9 @@ constexpr int PS6 = 8;                    // LDS stack entries per lane.  7.5 % 
                                           // tests/tools/trip_stats.sh), but more rows gain nothing: 9 rows with 123 cached
                                           // records (still eight workgroups per CU) measure the same, 10 rows lose 5 % --
                                           // launch pipelining lives on the eighth workgroup slot of a CU
-constexpr uint32_t TOP6_STRIDE = 80;      // bytes per cached record (64 + 16 padding): 10 KB
+constexpr uint32_t TOP6_STRIDE = 64;      // bytes per cached record.  (80 with 16 bytes of padding spread the lanes of a
+                                          // ds_read_b128 over more banks, but LDS reads cost a trip nothing measurable and 48
+                                          // more records do: +2 %, profiles/r02_experiments.txt)
 
 // The six slab distances of one child box (extend.cl:31-37), correctly rounded:
 //   t = a / d  as  q0 = a * y;  r = fma(-d, q0, a);  q = fma(r, y, q0),   y = RN32(1/d)
