@@ -147,7 +147,7 @@ struct uvrt_ctx {
     BatchSet bs[2];
     int b_set = 0;                        // the set of the traced batch (b_count > 0) / of the last one
     uint64_t b_chunks = 0;                // chunks traced so far: consecutive chunks alternate over the launch lanes
-    int32_t b_repl = 64;                  // deposit replicas per plane of the traced batch
+    int32_t b_repl = 16;                  // deposit replicas per plane of the traced batch
     std::vector<DevBuf> b_recs;           // [group]
     struct RecsKey { float ox = 0, oz = 0; const uint32_t* perm = nullptr; bool valid = false; };
     std::vector<RecsKey> b_recs_key;      // what b_recs[g] holds
@@ -598,8 +598,11 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
                           &c->dosage}) b->release();
         if ((rc = c->photon_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         if ((rc = c->max_map.ensure((size_t)T * 8, true, c->stream))) return rc;
-        // up to 64 deposit replicas, at most 64 MiB in total
-        int R = c->replicas_knob > 0 ? c->replicas_knob : 64;
+        // 16 deposit replicas (two per XCD: a workgroup deposits into replica blockIdx % 16), at most 64 MiB in
+        // total.  Fewer than 8 serialise on the hot triangles' counters; more than ~24 push the planes out of L2 and
+        // every wave then waits for its deposits' memory round trips (profiles/r02_experiments.txt: 64 replicas cost
+        // the batched step 5 %)
+        int R = c->replicas_knob > 0 ? c->replicas_knob : 16;
         while (R > 1 && (size_t)R * (size_t)T * 4 > ((size_t)64 << 20)) R >>= 1;
         c->replicas = R;
         if ((rc = c->counts.ensure((size_t)R * (size_t)T * 4, true, c->stream))) return rc;
@@ -1123,10 +1126,10 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     if (int rc = set_device(c)) return rc;
     const int64_t n_pad = (n + 63) / 64 * 64;
     // deposit replicas per plane: the contention on a hot triangle's counter grows with the rays per plane
-    // (64 replicas for 2 M rays; measured in profiles/r01_v6_experiments.txt), and every replica is read and
-    // zeroed again by the replay -- a shard of a launch gets by with proportionally fewer
+    // (16 replicas for 2 M rays), and every replica is read and zeroed again by the replay -- a shard of a launch
+    // gets by with 8 (one per XCD)
     int R = c->replicas;
-    while (R > 4 && (int64_t)R * 32768 > 2 * n) R >>= 1;
+    while (R > 8 && (int64_t)R * 131072 > 2 * n) R >>= 1;
     if ((uint64_t)count * (uint64_t)n_pad >= ((uint64_t)1 << 30) || (uint64_t)count * (uint64_t)R * (uint64_t)c->T >= ((uint64_t)1 << 32))
         return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: %d launches x %lld rays exceed one batch (2^30 ray slots, 2^32 counters)", count, (long long)n);
 
