@@ -476,6 +476,20 @@ __device__ __forceinline__ int run7(Lane6& L, const ExtendParams& p, uint32_t st
     return code;
 }
 
+// A ray outside the proof conditions of the packed exact division (a direction component zero, NaN, > 1 or
+// < 2^-60; an origin height that is tiny but not zero, or huge): it runs the IEEE-division form of the step.
+// Range tests on the bit patterns: |x| in [lo, hi]  <=>  bits(|x|) - bits(lo) <= bits(hi) - bits(lo) as unsigned.
+__device__ __forceinline__ bool outside_proof_conditions(float4 rec)
+{
+    const uint32_t lo = 0x21800000u /* 2^-60 */, one = 0x3F800000u;
+    const uint32_t ux = (__float_as_uint(rec.x) & 0x7FFFFFFFu) - lo, uy = (__float_as_uint(rec.y) & 0x7FFFFFFFu) - lo,
+                   uz = (__float_as_uint(rec.z) & 0x7FFFFFFFu) - lo;
+    const uint32_t worst = max(max(ux, uy), uz);
+    const uint32_t uo = __float_as_uint(rec.w) & 0x7FFFFFFFu;                   // |origin y|
+    const uint32_t ylo = 0x0D800000u /* 2^-100 = 7.888609e-31f */, yhi = 0x4E6E6B28u /* 1e9f */;
+    return worst > one - lo || (uo != 0u && uo - ylo > yhi - ylo);
+}
+
 template <int LEAFP, bool RECORD, bool TOP, bool OCL>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
@@ -568,10 +582,14 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                         const uint32_t my = gb * 64u + (v & 63u);
                         // plane (= launch of a batched trace) of the batch: gb / plane_batches, exact after one
                         // correction step (gb < 2^24 is exact in f32, the rounded reciprocal is off by < 1)
-                        uint32_t pl = (uint32_t)((float)gb * plane_inv);
-                        int32_t within = (int32_t)(gb - pl * p.plane_batches);
-                        if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
-                        else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
+                        uint32_t pl = 0;
+                        int32_t within = (int32_t)gb;
+                        if (p.plane_stride != 0) {               // wave-uniform: a launch of its own is one plane
+                            pl = (uint32_t)((float)gb * plane_inv);
+                            within = (int32_t)(gb - pl * p.plane_batches);
+                            if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
+                            else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
+                        }
                         if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
                             set_in_place(plane_off, pl * p.plane_stride);
                             const float4 rec = p.rays[my];
@@ -585,11 +603,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                             if (RECORD) { slot = my; live = true; }
                             set_in_place(L.sp, 0);
                             set_in_place(L.cur, root6);
-                            const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
-                            const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
-                            spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
-                                   !(adx <= 1.0f) || !(ady <= 1.0f) || !(adz <= 1.0f) ||
-                                   (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0;
+                            spec = outside_proof_conditions(rec) || p.force_exact != 0;
                         }
                     }
                     cursor += (uint32_t)nidle;
@@ -634,10 +648,14 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                     const uint32_t my = gb * 64u + (v & 63u);
                     // plane (= launch of a batched trace) of the batch: gb / plane_batches, exact after one
                     // correction step (gb < 2^24 is exact in f32, the rounded reciprocal is off by < 1)
-                    uint32_t pl = (uint32_t)((float)gb * plane_inv);
-                    int32_t within = (int32_t)(gb - pl * p.plane_batches);
-                    if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
-                    else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
+                    uint32_t pl = 0;
+                    int32_t within = (int32_t)gb;
+                    if (p.plane_stride != 0) {               // wave-uniform: a launch of its own is one plane
+                        pl = (uint32_t)((float)gb * plane_inv);
+                        within = (int32_t)(gb - pl * p.plane_batches);
+                        if (within < 0) { --pl; within += (int32_t)p.plane_batches; }
+                        else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
+                    }
                     if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
                         set_in_place(plane_off, pl * p.plane_stride);
                         const float4 rec = p.rays[my];
@@ -651,11 +669,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                         if (RECORD) { slot = my; live = true; }
                         set_in_place(L.sp, 0);
                         set_in_place(L.cur, root6);
-                        const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
-                        const float dmin = 8.6736174e-19f;     // 2^-60 (also catches zero and NaN components)
-                        spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
-                               !(adx <= 1.0f) || !(ady <= 1.0f) || !(adz <= 1.0f) ||
-                               (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0;
+                        spec = outside_proof_conditions(rec) || p.force_exact != 0;
                     }
                 }
                 cursor += (uint32_t)nidle;
