@@ -129,3 +129,36 @@ def test_packed_three_instruction_division_equals_ieee_quotient(tmp_path):
     L.check.restype = ctypes.c_long
     L.check.argtypes = [ctypes.c_long, ctypes.c_uint64]
     assert L.check(30_000_000, 88172645463325252) == 0
+
+
+def test_proof_condition_range_tests_on_bit_patterns():
+    """uvrt_extend6.hip outside_proof_conditions(): the refill decides with unsigned range tests on the bit patterns
+    (|x| in [lo, hi] <=> bits(|x|) - bits(lo) <= bits(hi) - bits(lo)) which rays leave the packed exact division;
+    this is the float-comparison form the proof conditions are stated in, restated both ways in numpy."""
+    import itertools
+    rng = np.random.default_rng(7)
+
+    def by_floats(r):
+        ay, a = np.abs(r[:, 3]), np.abs(r[:, :3])
+        with np.errstate(invalid="ignore"):
+            return ((~(a >= np.float32(8.6736174e-19))).any(1) | (~(a <= np.float32(1.0))).any(1) |
+                    ((ay != 0) & (ay < np.float32(7.888609e-31))) | (~(ay <= np.float32(1e9))))
+
+    def by_bits(r):
+        u = r.view(np.uint32) & np.uint32(0x7FFFFFFF)
+        lo, one = np.uint32(0x21800000), np.uint32(0x3F800000)
+        worst = (u[:, :3] - lo).max(1)                                   # wraps below lo
+        uo, ylo, yhi = u[:, 3], np.uint32(0x0D800000), np.uint32(0x4E6E6B28)
+        return (worst > one - lo) | ((uo != 0) & ((uo - ylo) > (yhi - ylo)))
+
+    assert np.float32(8.6736174e-19).view(np.uint32) == 0x21800000 and np.float32(7.888609e-31).view(np.uint32) == 0x0D800000
+    assert np.float32(1e9).view(np.uint32) == 0x4E6E6B28
+    x = rng.integers(0, 2 ** 32, size=(1 << 20, 4), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    f32 = np.float32
+    edge = np.array([0.0, -0.0, 8.6736174e-19, np.nextafter(f32(8.6736174e-19), f32(0)), 1.0, np.nextafter(f32(1), f32(2)),
+                     7.888609e-31, np.nextafter(f32(7.888609e-31), f32(0)), 1e9, np.nextafter(f32(1e9), f32(2e9)),
+                     np.inf, np.nan, 1e-45, 0.5, -0.5, -1.0], dtype=np.float32)
+    e = np.array(list(itertools.product(edge, repeat=4)), dtype=np.float32)
+    with np.errstate(over="ignore"):
+        for arr in (x, e):
+            assert np.array_equal(by_floats(arr), by_bits(arr))
