@@ -9,16 +9,21 @@ rooms/C046_1.glb is absent from the reference checkout, so its stand-in is the r
 testroomopt.glb (44 866 triangles vs 46 252); "1920x1080" = 2 073 600 photons per lamp launch; "8-bounce" =
 8 waves (iterations) of the reference's one-segment photon pass (the reference has no bounces); lamp 0 of
 positions/lange_route.xml; SEED_0 = 0.  `--scene soup:T` swaps in a synthetic T-triangle scene that does not
-fit in L2.
+fit in L2.  `--route` makes the reference's own DEFAULT workload the headline instead: all 12 lamps
+of lange_route.xml x 10 iterations x ((2^25 / 12) & ~1) photons (raytracer.h:30-32, myapp.cpp:156-170); the
+default run reports it beside the headline (`route_workload`).
 
 One STEP = one whole computation: ResetDosageMap, then per wave generate -> extend -> accumulate and Shade
 (computeDosage + dosageToColor), then a sync.  Inputs (scene, BVH) are resident in HBM before the timed region.
-`--mode batched` (default) runs it as RayTracer::ComputeIterationsBatched (include/uvrt.h "batched tracing": the
-waves traced first in fused launches of a few waves each on two side streams, then accumulate + Shade replayed
-per wave on the context's stream while the next computation is already being traced: the same arithmetic, the
-same bits); `--mode loop` is the reference's host loop call by call (myapp.cpp:156-163) with the library's
-two-stream launch pipelining.  Both are timed at N = 1; `value` is the selected mode's, the other one is
-reported under `other_modes`.
+Modes at N = 1 (`value` is the selected one's, the others are reported under `other_modes`):
+  batched (default)   RayTracer::ComputeIterationsBatched -- an API EXTENSION the reference's caller does not have
+                      (include/uvrt.h "batched tracing"): the waves traced first in fused launches of a few waves
+                      each on two side streams, then accumulate + Shade replayed per wave on the context's stream
+                      while the next computation is already being traced: the same arithmetic, the same bits;
+  loop                the reference's host loop call by call (myapp.cpp:156-163) with the library's two-stream
+                      launch pipelining, no host sync inside a computation;
+  loop_sync           the same loop with the reference's clFinish after every iteration (myapp.cpp:165): what an
+                      unmodified MyApp::Tick sees.
 
 N > 1 (one process per GPU): STRONG scaling is the headline -- BASELINE configs[3]: every launch is split by
 global-id range over the ranks ("pixel tiles"), each rank deposits into private int32 planes, ONE RCCL
@@ -40,6 +45,8 @@ sys.path.insert(0, ROOT)
 
 PHOTONS = 1920 * 1080
 WAVES = 8
+ROUTE_PHOTONS = 1 << 25      # raytracer.h:30 photonCount
+ROUTE_ITERATIONS = 10        # raytracer.h:32 maxIterations
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 
 
@@ -138,6 +145,24 @@ class _Scene:
     pass
 
 
+def issue_model_utilisation(m, rays, seconds):
+    """Utilisation of each unit while `rays` rays are traced in `seconds` of wall time: the kernel's per-ray
+    instruction / lookup / byte counts (rocprofv3 PMC passes, deterministic per launch; tests/tools/issue_model.py)
+    priced with the issue rates calibrated on this GPU type (tests/tools/valu_calib.hip,
+    profiles/r02_valu_calibration.txt).  Returns (utilisation per unit, [lower, upper] of the VALU figure)."""
+    k, pr, vc = m["constants"], m["per_ray"], m["valu_issue_cycles"]
+    simd_cycles = k["simds"] * k["clock_hz"] * seconds
+    cu_cycles = k["cus"] * k["clock_hz"] * seconds
+    util = {
+        "valu_issue": pr["valu_issue_cycles"] * rays / simd_cycles,
+        "salu_issue": pr["salu_insts"] * rays / cu_cycles,
+        "l1_lookup": pr["l1_lane_lookups"] * rays / (cu_cycles * k["l1_lookups_per_clk_per_cu"]),
+        "hbm": pr["hbm_bytes"] * rays / seconds / k["hbm_peak_bytes_per_s"],
+    }
+    scale = rays / m["rays_per_launch"]
+    return util, [vc["lower"] * scale / simd_cycles, vc["upper"] * scale / simd_cycles]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,18 +170,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--photons", type=int, default=PHOTONS)
     ap.add_argument("--waves", type=int, default=WAVES, help="waves (iterations) of the computation")
-    ap.add_argument("--mode", choices=["batched", "loop"], default="batched",
-                    help="N = 1: batched (default) = RayTracer::ComputeIterationsBatched; loop = the reference's host loop "
-                         "call by call.  N > 1 always runs the batched, sharded computation")
+    ap.add_argument("--mode", choices=["batched", "loop", "loop_sync"], default="batched",
+                    help="N = 1: batched (default) = RayTracer::ComputeIterationsBatched (an API extension); loop = the "
+                         "reference's host loop call by call; loop_sync = that loop with the reference's device sync after "
+                         "every iteration (myapp.cpp:165).  N > 1 always runs the batched, sharded computation")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1 headline: strong (default, BASELINE configs[3]: launches split by global-id range, one "
                          "int32 all-reduce of the count planes per computation) or weak (configs[4]: whole launches dealt "
                          "to ranks, 8 waves per GPU); the other one is measured too and reported beside it")
     ap.add_argument("--scene", default=None, help="a .glb file, or soup:T for a synthetic T-triangle scene")
+    ap.add_argument("--route", action="store_true",
+                    help="headline = the reference's default workload: 12 lamps x 10 iterations x ((2^25 / 12) & ~1) photons "
+                         "(raytracer.h:30-32, positions/lange_route.xml, myapp.cpp:156-170)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lean", action="store_true",
-                    help="profiling aid: only the headline mode (no other-mode leg, no single-computation leg), so that a "
-                         "kernel trace / PMC run holds nothing but the timed kind of launch")
+                    help="profiling aid: only the headline mode (no other-mode, single-computation, cold or route leg), so "
+                         "that a kernel trace / PMC run holds nothing but the timed kind of launch")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: launches do not overlap")
     ap.add_argument("--sort-bits", type=int, default=None)
     ap.add_argument("--variant", type=int, default=None)
@@ -166,6 +195,9 @@ def main():
     ap.add_argument("--flavour", type=int, default=0, choices=[0, 1],
                     help="arithmetic flavour of IntersectTri (include/uvrt.h uvrt_set_flavour): 0 = canonical strict "
                          "(SURVEY 8c), 1 = the fused cross/dot ROCm's OpenCL gives the reference's extend.cl on gfx950")
+    ap.add_argument("--seed-mode", type=int, default=0, choices=[0, 1],
+                    help="SEED semantics of generate.cl (include/uvrt.h uvrt_set_seed_mode): 0 = canonical (SURVEY 8c), "
+                         "1 = what the reference's kernel does on gfx950; with --flavour 1 the reference's live kernel chain")
     args = ap.parse_args()
 
     import numpy as np
@@ -182,8 +214,10 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    if world > 1 and args.mode == "loop":
-        raise SystemExit("--mode loop is a single-GPU mode (N > 1 runs the sharded batched computation)")
+    if world > 1 and args.mode != "batched":
+        raise SystemExit("--mode %s is a single-GPU mode (N > 1 runs the sharded batched computation)" % args.mode)
+    if args.route and (args.scene or world > 1):
+        raise SystemExit("--route is the single-GPU test-room workload")
     ndev = torch.cuda.device_count()
     rehearsal = world > ndev          # more ranks than GPUs: ranks share devices, collectives over gloo
     dev_index = local_rank % ndev
@@ -218,11 +252,18 @@ def main():
             glb = args.scene
             scene_label = os.path.basename(glb)
         rt = host.RayTracer(glb, route_xml, device=dev_index)
-    default_config = (args.scene is None and args.photons == PHOTONS and args.waves == WAVES)
+    all_lamps = rt.lamps()
+    if args.route:
+        args.photons, args.waves = ROUTE_PHOTONS, ROUTE_ITERATIONS
+    default_config = (args.scene is None and args.photons == PHOTONS and args.waves == WAVES and not args.route)
 
-    rt.set_lamps(rt.lamps()[:1])              # lamp 0
-    rt.photonCount = args.photons
-    rt.maxIterations = args.waves
+    def configure(lamps, photon_count, iterations):
+        rt.set_lamps(lamps)
+        rt.photonCount = photon_count
+        rt.maxIterations = iterations
+
+    headline_lamps = all_lamps if args.route else all_lamps[:1]
+    configure(headline_lamps, args.photons, args.waves)
     # One real (non-default) torch stream carries BOTH the uvrt kernels and any torch collective, so reductions
     # are ordered after the last deposit and before the replay without host syncs.
     stream = torch.cuda.Stream(device=device)
@@ -236,10 +277,12 @@ def main():
     if args.no_pipeline:
         rt.ctx.set_pipeline(False)
     rt.ctx.set_flavour(args.flavour)
+    rt.ctx.set_seed_mode(args.seed_mode)
     if args.wide:
         rt.ctx.set_wide_bvh(True)
     n_launch = rt.photonsPerLight
-    lamp = rt.lamps()[0]
+    n_lamps = len(headline_lamps)
+    lamp = headline_lamps[0]
     lp = (lamp[0], float(np.float32(np.float32(rt.mesh.floorHeight) + np.float32(rt.lightHeight))), lamp[1])
 
     # ---- the sharded (strong) computation: ray ranges + one collective per batch ---------------------------
@@ -272,16 +315,26 @@ def main():
             rt.photonMapSize = args.waves * n_launch
             rt.currIterations = args.waves
         else:
-            rt.ComputeIterationsBatched(args.waves)
+            rt.ComputeIterationsBatched(rt.maxIterations)
 
     def step_loop():
         rt.ctx.seed = 0
         rt.ResetDosageMap()
-        for _ in range(args.waves):           # myapp.cpp:156-163
+        for _ in range(rt.maxIterations):     # myapp.cpp:156-163
             rt.ComputeDosageMap()
             rt.Shade()
             rt.currIterations = rt.currIterations + 1
 
+    def step_loop_sync():
+        rt.ctx.seed = 0
+        rt.ResetDosageMap()
+        for _ in range(rt.maxIterations):     # myapp.cpp:156-165: clFinish after every iteration
+            rt.ComputeDosageMap()
+            rt.Shade()
+            rt.currIterations = rt.currIterations + 1
+            rt.Sync()
+
+    STEP = {"batched": step_batched, "loop": step_loop, "loop_sync": step_loop_sync}
     reducer = [None]
 
     def step_weak():
@@ -319,42 +372,112 @@ def main():
             el = float(tmax.item())
         return el
 
+    def one_synced(step):
+        sync_all()
+        t1 = time.perf_counter()
+        step()
+        sync_all()
+        return (time.perf_counter() - t1) * 1e3
+
+    def median_synced(step, k):
+        sm = sorted(one_synced(step) for _ in range(k))
+        return sm[len(sm) // 2]
+
     def crc(a):
         return "%08x" % zlib.crc32(a.tobytes())
 
-    rays_per_step = args.waves * n_launch
+    golden_path = os.path.join(ROOT, "tests", "golden", "bench_dose_crc.json")
+    golden = json.load(open(golden_path)) if os.path.exists(golden_path) else {}
+
+    rays_per_step = args.waves * n_launch * n_lamps
     other_modes = {}
     weak = strong = None
     single_ms = None
     ext_ms = ext_launches = None
+    cold = route_leg = None
     timing_steps = max(1, min(3, args.steps))
+    few = max(1, min(5, args.steps))
 
     if world == 1:
-        headline = step_batched if args.mode == "batched" else step_loop
+        headline = STEP[args.mode]
         elapsed = timed(headline, args.warmup, args.steps)
         # the result of the TIMED region itself (the last of its steps), read before anything else runs
         dose_timed = rt.read_dosage()
-        # one computation on its own, bracketed by syncs (the reference syncs every iteration, myapp.cpp:165;
-        # `value` is the steady-state rate of back-to-back computations)
-        sm = []
-        for _ in range(0 if args.lean else max(1, min(5, args.steps))):
-            sync_all()
-            t1 = time.perf_counter()
-            headline()
-            sync_all()
-            sm.append((time.perf_counter() - t1) * 1e3)
-        sm.sort()
-        single_ms = sm[len(sm) // 2] if sm else None
-        # the other mode, for comparison, and its dose
         if not args.lean:
-            other = step_loop if args.mode == "batched" else step_batched
-            el_o = timed(other, args.warmup, args.steps)
-            other_modes["loop" if args.mode == "batched" else "batched"] = {
-                "value": round(rays_per_step * args.steps / el_o / 1e6, 2), "ms_per_step": round(el_o / args.steps * 1e3, 4),
-                "dose_crc32": crc(rt.read_dosage())}
+            # one computation on its own, bracketed by syncs (`value` is the steady-state rate of back-to-back
+            # computations)
+            single_ms = median_synced(headline, few)
+            # the other modes, for comparison, and their dose
+            for m in ("batched", "loop", "loop_sync"):
+                if m == args.mode:
+                    continue
+                el_o = timed(STEP[m], args.warmup, args.steps)
+                other_modes[m] = {"value": round(rays_per_step * args.steps / el_o / 1e6, 2),
+                                  "ms_per_step": round(el_o / args.steps * 1e3, 4), "dose_crc32": crc(rt.read_dosage())}
+            other_modes["loop_sync" if args.mode != "loop_sync" else "loop"]["note"] = (
+                "loop_sync = the reference's own host loop INCLUDING its clFinish after every iteration (myapp.cpp:159-165): "
+                "what an unmodified MyApp::Tick sees; loop = the same calls without that sync; batched is an API extension")
+            # the arithmetic + SEED semantics the reference's own kernels have on gfx950 (uvrt_set_seed_mode(1) +
+            # uvrt_set_flavour(1): rays, counts and f64 maps equal the reference's live kernel chain,
+            # tests/test_gpu_reference_kernels.py), same step, same mode
+            if args.flavour == 0 and args.seed_mode == 0:
+                rt.ctx.set_flavour(1)
+                rt.ctx.set_seed_mode(1)
+                el_r = timed(headline, 1, args.steps)
+                crc_r = crc(rt.read_dosage())
+                exp_r = golden.get("seed1_flavour1") if default_config else None
+                other_modes["reference_live_chain_semantics"] = {
+                    "value": round(rays_per_step * args.steps / el_r / 1e6, 2), "ms_per_step": round(el_r / args.steps * 1e3, 4),
+                    "dose_crc32": crc_r, "dose_crc32_expected": exp_r, "mode": args.mode,
+                    "note": "--seed-mode 1 --flavour 1: every work-item reads SEED_{k-1}, a negative seed sum converts to 0, fused "
+                            "cross/dot in IntersectTri -- what the reference's cl/*.cl do on this GPU; expected CRC = the oracle's "
+                            "(tests/golden/make_bench_crc.py)"}
+                rt.ctx.set_flavour(0)
+                rt.ctx.set_seed_mode(0)
+                if exp_r is not None and crc_r != exp_r:
+                    raise SystemExit("bench: seed-mode-1 / flavour-1 dose CRC %s differs from the oracle's %s" % (crc_r, exp_r))
+            # ---- a lamp position the context has never seen: the hot-record set-up (uvrt_hotset.hip) is inside ------
+            if len(all_lamps) > 1 and not args.route:
+                configure(all_lamps[1:2], args.photons, args.waves)
+                cold_ms = one_synced(headline)
+                warm_ms = median_synced(headline, few)
+                cold = {"new_lamp_first_computation_ms": round(cold_ms, 4), "same_lamp_warm_ms": round(warm_ms, 4),
+                        "cold_over_warm": round(cold_ms / warm_ms, 4), "mode": args.mode,
+                        "note": "lamp 1 of the route, first computation at a lamp position the context has not seen (visit "
+                                "statistics + hot-record selection + renumbering + per-launch records inside), against the median "
+                                "of the next %d at the same lamp; each bracketed by device syncs; buffers already allocated" % few}
+                configure(headline_lamps, args.photons, args.waves)
+        # ---- the reference's default workload: 12 lamps x 10 iterations x 2 796 202 photons -----------------------
+        if default_config and not args.lean and len(all_lamps) > 1:
+            configure(all_lamps, ROUTE_PHOTONS, ROUTE_ITERATIONS)
+            n_route = rt.photonsPerLight
+            rays_route = ROUTE_ITERATIONS * len(all_lamps) * n_route
+            # buffers of this size are allocated by a computation over SHIFTED lamps, so that the first computation of
+            # the real route below is cold only in what belongs to the lamps (hot records, per-launch records)
+            rt.set_lamps([(l[0] + 0.0078125, l[1] - 0.0078125, l[2]) for l in all_lamps])
+            one_synced(headline)
+            rt.set_lamps(all_lamps)
+            cold_ms = one_synced(headline)
+            crc_cold = crc(rt.read_dosage())
+            k_route = max(1, min(3, args.steps))
+            el_route = timed(headline, 0, k_route)
+            crc_route = crc(rt.read_dosage())
+            exp_route = golden.get("route_flavour%d" % args.flavour) if args.seed_mode == 0 else None
+            route_leg = {"workload": "lange_route.xml: %d lamps x %d iterations x %d photons = %d rays per computation (raytracer.h:30-32, "
+                                     "myapp.cpp:156-170)" % (len(all_lamps), ROUTE_ITERATIONS, n_route, rays_route),
+                         "mode": args.mode, "ms_per_computation": round(el_route / k_route * 1e3, 3),
+                         "mray_s": round(rays_route * k_route / el_route / 1e6, 1), "computations_timed": k_route,
+                         "cold_first_computation_ms": round(cold_ms, 3),
+                         "cold_over_warm": round(cold_ms / (el_route / k_route * 1e3), 4),
+                         "dose_crc32": crc_route, "dose_crc32_cold": crc_cold, "dose_crc32_expected": exp_route,
+                         "note": "cold = the first computation over these 12 lamp positions (12 hot-record set-ups inside), bracketed "
+                                 "by syncs, buffers allocated beforehand; expected CRC = the oracle's (tests/golden/make_bench_crc.py)"}
+            if crc_cold != crc_route or (exp_route is not None and crc_route != exp_route):
+                raise SystemExit("bench: route workload dose CRC %s / %s differs from the oracle's %s" % (crc_cold, crc_route, exp_route))
+            configure(headline_lamps, args.photons, args.waves)
         # timing pass for the roofline: the headline step with HIP events around the extend launches on their
-        # stream (loop mode: launch pipelining off, so the kernels of neighbouring waves do not overlap)
-        if args.mode == "loop":
+        # stream (loop modes: launch pipelining off, so the kernels of neighbouring waves do not overlap)
+        if args.mode != "batched":
             rt.ctx.set_pipeline(False)
         rt.ctx.set_timing(True)
         rt.ctx.extend_time_ms()                    # drop anything recorded so far
@@ -407,15 +530,20 @@ def main():
         cpu = None
         census = None
         expected = None
-        golden_crc = os.path.join(ROOT, "tests", "golden", "bench_dose_crc.json")
-        if default_config and os.path.exists(golden_crc) and not (world > 1 and args.scaling == "weak"):
-            expected = json.load(open(golden_crc)).get("flavour%d" % args.flavour)
+        if default_config and not (world > 1 and args.scaling == "weak"):
+            expected = golden.get("seed1_flavour1" if (args.seed_mode == 1 and args.flavour == 1) else
+                                  ("flavour%d" % args.flavour) if args.seed_mode == 0 else "-")
+        if args.route and args.seed_mode == 0:
+            expected = golden.get("route_flavour%d" % args.flavour)
         if world == 1 and not args.no_cpu_baseline:
             orc = g.load_oracle()
             if oscene is None:
                 oscene = orc.Scene(glb)
-            cpu, census, ref_dose = cpu_baseline(oscene, orc.load_route(route_xml), args.waves, args.photons, args.flavour)
-            if ref_dose is not None:
+            # the CPU leg always times the BASELINE workload shape (lamp 0, 8 waves of the launch size): with --route the
+            # sample is 8 waves of 2 796 202 photons from lamp 0, not the whole 335 M-ray route
+            cpu, census, ref_dose = cpu_baseline(oscene, orc.load_route(route_xml), WAVES if args.route else args.waves,
+                                                 n_launch, args.flavour)
+            if ref_dose is not None and not args.route and args.seed_mode == 0:
                 same = np.array_equal(dose_timed.view(np.uint32), ref_dose.view(np.uint32))
                 cpu["gpu_dose_bit_identical"] = bool(same)
                 cpu["checked"] = "dose read right after the timed steps, before any other pass"
@@ -423,7 +551,8 @@ def main():
                     raise SystemExit("bench: the dose of the timed region differs from the oracle's")
             else:
                 cpu["gpu_dose_bit_identical"] = None
-                cpu["checked"] = "the CPU sample was cut short of the full step: no dose comparison in this run"
+                cpu["checked"] = ("the CPU sample is not the timed step (cut short, --route or --seed-mode 1): the dose is checked "
+                                  "against the committed oracle CRC instead")
         if expected is not None and crc_timed != expected:
             raise SystemExit("bench: dose CRC %s of the timed region differs from the committed %s" % (crc_timed, expected))
         if census is None and os.path.exists(census_path()) and default_config:
@@ -433,57 +562,56 @@ def main():
         if ext_launches:
             avg_ms = ext_ms / max(ext_launches, 1)
             rays_per_extend = rays_per_step * timing_steps / max(ext_launches, 1)
-            model_path = os.path.join(ROOT, "profiles", "extend_issue_model_%s.json" % args.mode)
+            model_mode = "batched" if args.mode == "batched" else "loop"
+            model_path = os.path.join(ROOT, "profiles", "extend_issue_model_%s.json" % model_mode)
             if not os.path.exists(model_path):
                 model_path = os.path.join(ROOT, "profiles", "extend_issue_model.json")
-            if os.path.exists(model_path) and args.scene is None and not args.wide:
-                # The binding resource, priced with the per-ray instruction / lookup / byte counts of the kernel
-                # (rocprofv3 PMC passes, deterministic per launch; tests/tools/issue_model.py) and the issue rates
-                # calibrated on this GPU type (tests/tools/valu_calib.hip, profiles/r02_valu_calibration.txt);
-                # the DURATION is this run's.
+            step_sec = elapsed / args.steps
+            if os.path.exists(model_path) and args.scene is None and not args.wide and not args.route:
+                # The binding resource at the level the driver times: the whole step.  Per-ray counts x the step's rays
+                # over the step's wall time -- NOT over a launch's duration, which overlaps its neighbour's on the
+                # other launch lane.  The per-launch view is kept beside it, labelled.
                 m = json.load(open(model_path))
                 k = m["constants"]
                 pr = m["per_ray"]
-                sec = avg_ms * 1e-3
-                simd_cycles = k["simds"] * k["clock_hz"] * sec
-                cu_cycles = k["cus"] * k["clock_hz"] * sec
-                util = {
-                    "valu_issue": pr["valu_issue_cycles"] * rays_per_extend / simd_cycles,
-                    "salu_issue": pr["salu_insts"] * rays_per_extend / cu_cycles,
-                    "l1_lookup": pr["l1_lane_lookups"] * rays_per_extend / (cu_cycles * k["l1_lookups_per_clk_per_cu"]),
-                    "hbm": pr["hbm_bytes"] * rays_per_extend / sec / k["hbm_peak_bytes_per_s"],
-                }
-                bound = max(util, key=util.get)
-                vc = m["valu_issue_cycles"]
-                scale = rays_per_extend / m["rays_per_launch"]
-                roof = {"bound": bound, "kernel": kernel_name,
-                        "achieved": round(pr["valu_issue_cycles"] * rays_per_extend / sec / 1e9, 1),
+                util_step, bracket_step = issue_model_utilisation(m, rays_per_step, step_sec)
+                util_launch, bracket_launch = issue_model_utilisation(m, rays_per_extend, avg_ms * 1e-3)
+                roof = {"bound": "valu_issue", "kernel": kernel_name, "level": "step (driver-timed ms_per_step)",
+                        "achieved": round(pr["valu_issue_cycles"] * rays_per_step / step_sec / 1e9, 1),
                         "peak": round(k["simds"] * k["clock_hz"] / 1e9, 1), "unit": "G VALU issue-cycles/s",
-                        "frac": round(util["valu_issue"], 4),
-                        "frac_bracket": [round(vc["lower"] * scale / simd_cycles, 4), round(vc["upper"] * scale / simd_cycles, 4)],
+                        "frac": round(util_step["valu_issue"], 4),
+                        "frac_bracket": [round(bracket_step[0], 4), round(bracket_step[1], 4)],
                         "lane_utilisation": round(m["lane_utilisation"], 4),
-                        "useful_lane_frac": round(util["valu_issue"] * m["lane_utilisation"], 4),
-                        "utilisation_of_every_unit": {u: round(v, 4) for u, v in util.items()},
-                        "wave_time_waiting_on_memory": round(m["wave_wait_frac"], 3) if m.get("wave_wait_frac") else None,
+                        "useful_lane_frac": round(util_step["valu_issue"] * m["lane_utilisation"], 4),
+                        "step_level": {u: round(v, 4) for u, v in util_step.items()},
                         "traffic": round(pr["hbm_bytes"] * rays_per_extend),
-                        "traffic_is": "static: PMC FETCH_SIZE x 2 + WRITE_SIZE per launch of %s (not collected in this run)" % m["source"],
-                        "rays_per_launch": int(rays_per_extend), "avg_launch_ms": round(avg_ms, 4),
-                        "extend_mray_s": round(rays_per_extend / avg_ms / 1e3, 1),
+                        "traffic_is": "static: PMC FETCH_SIZE x 2 + WRITE_SIZE per extend launch of %s (not collected in this run)" % m["source"],
+                        "hbm_measured_frac_of_peak": round(util_step["hbm"], 4),
+                        "per_launch": {"rays_per_launch": int(rays_per_extend), "avg_launch_ms": round(avg_ms, 4),
+                                       "extend_mray_s": round(rays_per_extend / avg_ms / 1e3, 1),
+                                       "utilisation_over_the_launch_wall_time": {u: round(v, 4) for u, v in util_launch.items()},
+                                       "valu_bracket": [round(bracket_launch[0], 4), round(bracket_launch[1], 4)],
+                                       "caveat": "in batched / pipelined modes two launches are co-resident: a launch's wall time "
+                                                 "is not machine time, so these understate the units' load; step_level is the figure"},
+                        "wave_time_waiting_on_memory": round(m["wave_wait_frac"], 3) if m.get("wave_wait_frac") else None,
                         "clock_assumed_ghz": k["clock_hz"] / 1e9,
                         "timing_pass": "%d step(s) after the timed region; HIP events around the extend launch on its stream" % timing_steps,
                         "model": "%s (%s)" % (os.path.relpath(model_path, ROOT), m.get("note", "")),
-                        "note": "no unit is saturated: the launch is latency-bound (waves spend about half their life in "
-                                "s_waitcnt on record fetches) with VALU issue the busiest unit; packed f32 saves "
-                                "instructions, not issue cycles (DESIGN.md 4)"}
-            if census is not None:
+                        "note": "per-ray counts (PMC) x rays per step / (ms_per_step x unit peak), rates calibrated on the box; VALU "
+                                "issue is the busiest unit, HBM carries a few per cent (the 5.7 MB record set lives in L2 / LDS); "
+                                "packed f32 saves instructions, not issue cycles (DESIGN.md 4a)"}
+            if census is not None and not args.route:
                 # SURVEY.md 8d's HBM-read figure (algorithmic bytes of the REFERENCE's layout, every node visit
                 # priced as a memory read): secondary on the L2-resident room, primary on a scene beyond L2
                 n = float(census["rays"])
                 bytes_per_ray = (32.0 + 8.0 + 32.0 * (1.0 + census["aabb_tests"] / n)
                                  + 68.0 * census["tri_tests"] / n + 4.0 * census["hits"] / n)
                 achieved = bytes_per_ray * rays_per_extend / (avg_ms * 1e-3) / 1e9
+                achieved_step = bytes_per_ray * rays_per_step / step_sec / 1e9
                 hbm_alg = {"algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "achieved_GBs": round(achieved, 1),
+                           "achieved_GBs_step_level": round(achieved_step, 1),
                            "peak_GBs": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "frac_step_level": round(achieved_step / HBM_PEAK_GBS, 4),
                            "note": "SURVEY 8d bookkeeping: every node visit priced as a memory read of the reference's "
                                    "32-B nodes / 64-B triangles; exceeds the peak where the scene is L2/LDS resident"}
                 if roof is None:
@@ -501,32 +629,40 @@ def main():
                          "accumulate + shade replayed per wave")
             par = (strong if args.scaling == "strong" else weak)["parallelism"]
         else:
-            step_text = ("generate + extend of all waves (batched), accumulate + shade replayed per wave" if args.mode == "batched"
-                         else "waves x (generate, extend, accumulate, shade)")
+            step_text = {"batched": "generate + extend of all waves (batched), accumulate + shade replayed per wave",
+                         "loop": "waves x (generate, extend, accumulate, shade)",
+                         "loop_sync": "waves x (generate, extend, accumulate, shade, device sync)"}[args.mode]
             par = "1 GPU"
+        lamp_text = ("all %d lamps of lange_route.xml" % n_lamps) if args.route else "lamp 0 of lange_route.xml"
         out = {
             "metric": "Mray/s (extend+shade) on C046_1.glb 1920x1080x8-bounce", "value": round(value, 2),
             "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, %d photons/launch x %d waves%s, lamp 0 of lange_route.xml, SEED_0=0; step = reset + %s + sync"
+            "config": {"workload": "%s, %d photons/launch x %d waves%s, %s, SEED_0=0; step = reset + %s + sync"
                                    % (scene_label, n_launch, args.waves, " per GPU" if (world > 1 and args.scaling == "weak") else "",
-                                      step_text),
+                                      lamp_text, step_text),
                        "triangles": rt.mesh.triangleCount, "rays_per_step": rays_per_step, "mode": args.mode,
-                       "launch_pipelining": bool(not args.no_pipeline), "flavour": args.flavour, "wide_bvh": bool(args.wide),
-                       "parallelism": par},
+                       "mode_is": ("batched = RayTracer::ComputeIterationsBatched, an API extension the reference's caller "
+                                   "(myapp.cpp:156-170) does not use; other_modes.loop / loop_sync are the drop-in figures"
+                                   if args.mode == "batched" else "the reference's host loop (myapp.cpp:156-165)"),
+                       "launch_pipelining": bool(not args.no_pipeline), "flavour": args.flavour, "seed_mode": args.seed_mode,
+                       "wide_bvh": bool(args.wide), "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,
             "dose_crc32": crc_timed, "dose_crc32_expected": expected, "dose_crc32_after_all_passes": crc(dose_after),
             "value_is": "steady-state throughput of back-to-back computations (one device sync after the last step)",
         }
         if world == 1:
-            if crc(dose_after) != crc_timed or any(v["dose_crc32"] != crc_timed for v in other_modes.values()):
+            same_semantics = [v["dose_crc32"] for k, v in other_modes.items() if k != "reference_live_chain_semantics"]
+            if crc(dose_after) != crc_timed or any(c != crc_timed for c in same_semantics):
                 raise SystemExit("bench: the passes disagree on the dose (%s / %s / %s)" % (crc_timed, other_modes, crc(dose_after)))
             if single_ms is not None:
                 out["single_computation"] = {"ms": round(single_ms, 4), "mray_s": round(rays_per_step / single_ms / 1e3, 1),
-                                             "note": "one step bracketed by device syncs, median of %d" % max(1, min(5, args.steps))}
+                                             "note": "one step bracketed by device syncs, median of %d" % few}
             out["other_modes"] = other_modes
+            out["cold_start"] = cold
+            out["route_workload"] = route_leg
         else:
             out["multi_gpu_check"] = {"dose_identical_on_all_ranks": ranks_agree, "photons_traced": rays_per_step}
             out["strong"] = strong

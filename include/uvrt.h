@@ -203,6 +203,9 @@ int uvrt_set_hot_records(uvrt_ctx* ctx, int32_t mode);
  * numbering are served from LDS.  Results do not depend on it.  NULL restores the breadth-first
  * order.  Reset by uvrt_set_scene. */
 int uvrt_set_record_perm(uvrt_ctx* ctx, const uint32_t* perm, int32_t n);
+/* test hook: the renumbering the launch of the last uvrt_generate uses (the caller's own, the automatic hot-record
+ * one, or the identity): out[i] = index of breadth-first record i, n = number of inner nodes; synchronises. */
+int uvrt_read_record_perm(uvrt_ctx* ctx, uint32_t* out, int32_t n);
 
 /* Launch pipelining (on by default): consecutive launches (generate, extend, accumulate and the Shade
  * that follows) alternate between the context's stream and an internal second stream with their own

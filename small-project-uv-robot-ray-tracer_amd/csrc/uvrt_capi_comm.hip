@@ -1,0 +1,173 @@
+// uvrt_capi_comm.hip -- the one collective of a sharded computation (RCCL over xGMI)
+// (the C ABI of include/uvrt.h over the HIP kernels; the context and its helpers are in uvrt_ctx.h)
+#include "uvrt_ctx.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl is opened at run time
+
+using namespace uvrt;
+using namespace uvrt_impl;
+
+// librccl is opened lazily with dlopen: a process that never shards (the common case) does not load it,
+// and one that already holds an RCCL (torch.distributed) gets that same library by its soname.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return UVRT_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return fail(UVRT_ERR_HIP, "uvrt_comm: cannot open librccl (%s)", dlerror());
+#define UVRT_SYM(field, sym)                                                                   \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(h, #sym);                                      \
+    if (!g_rccl.field) return fail(UVRT_ERR_HIP, "uvrt_comm: librccl lacks " #sym)
+    UVRT_SYM(GetUniqueId, ncclGetUniqueId);
+    UVRT_SYM(CommInitRank, ncclCommInitRank);
+    UVRT_SYM(CommInitAll, ncclCommInitAll);
+    UVRT_SYM(CommDestroy, ncclCommDestroy);
+    UVRT_SYM(AllReduce, ncclAllReduce);
+    UVRT_SYM(GroupStart, ncclGroupStart);
+    UVRT_SYM(GroupEnd, ncclGroupEnd);
+    UVRT_SYM(GetErrorString, ncclGetErrorString);
+#undef UVRT_SYM
+    g_rccl.lib = h;
+    return UVRT_OK;
+}
+#define RCCL_TRY(expr)                                                                         \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return fail(UVRT_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));        \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int uvrt_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(UVRT_ERR_INVALID, "uvrt_comm_unique_id: null pointer");
+    if (int rc = rccl_load()) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "the ABI hands the id over as 128 bytes");
+    RCCL_TRY(g_rccl.GetUniqueId((ncclUniqueId*)id128));
+    return UVRT_OK;
+}
+
+int uvrt_comm_init_rank(uvrt_ctx* c, const void* id128, int32_t rank, int32_t world)
+{
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_rank: bad argument");
+    if (c->comm) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_rank: the context already has a communicator");
+    if (int rc = rccl_load()) return rc;
+    if (int rc = set_device(c)) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return UVRT_OK;
+}
+
+int uvrt_comm_init_all(uvrt_ctx** ctxs, int32_t n)
+{
+    if (!ctxs || n < 1 || n > 64) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_all: bad argument");
+    int devs[64];
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->comm) return fail(UVRT_ERR_INVALID, "uvrt_comm_init_all: null context or communicator present");
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i])
+                return fail(UVRT_ERR_INVALID, "uvrt_comm_init_all: contexts %d and %d share device %d (RCCL wants one rank "
+                            "per device; uvrt_reduce_batch_group sums contexts of one device without it)", j, i, devs[i]);
+    }
+    if (int rc = rccl_load()) return rc;
+    ncclComm_t comms[64];
+    RCCL_TRY(g_rccl.CommInitAll(comms, n, devs));
+    for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_rank = i; ctxs[i]->comm_world = n; }
+    return UVRT_OK;
+}
+
+int uvrt_comm_destroy(uvrt_ctx* c)
+{
+    if (!c || !c->comm) return UVRT_OK;
+    if (g_rccl.lib) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+    }
+    c->comm = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+    return UVRT_OK;
+}
+
+int uvrt_reduce_batch(uvrt_ctx* c)
+{
+    if (!c || c->b_count <= 0) return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch: no traced batch");
+    if (!c->comm) return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch: no communicator (uvrt_comm_init_rank / uvrt_comm_init_all)");
+    if (int rc = uvrt_fold_batch(c)) return rc;
+    if (int rc = set_device(c)) return rc;
+    RCCL_TRY(g_rccl.AllReduce(c->bs[c->b_set].folded.p, c->bs[c->b_set].folded.p, (size_t)c->b_count * (size_t)c->T, ncclInt32, ncclSum,
+                              (ncclComm_t)c->comm, c->stream));
+    return UVRT_OK;
+}
+
+int uvrt_reduce_batch_group(uvrt_ctx** ctxs, int32_t n)
+{
+    if (!ctxs || n < 1) return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->b_count <= 0 || ctxs[i]->b_count != ctxs[0]->b_count || ctxs[i]->T != ctxs[0]->T)
+            return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: context %d holds no batch of the same shape", i);
+        if (int rc = uvrt_fold_batch(ctxs[i])) return rc;
+    }
+    if (n == 1) return UVRT_OK;
+    const size_t count = (size_t)ctxs[0]->b_count * (size_t)ctxs[0]->T;
+    if (ctxs[0]->comm) {          // one process, one device per context: a grouped RCCL all-reduce
+        if (int rc = rccl_load()) return rc;
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int i = 0; i < n; ++i) {
+            if (!ctxs[i]->comm) { (void)g_rccl.GroupEnd(); return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: context %d has no communicator", i); }
+            HIP_TRY(hipSetDevice(ctxs[i]->device));
+            RCCL_TRY(g_rccl.AllReduce(ctxs[i]->bs[ctxs[i]->b_set].folded.p, ctxs[i]->bs[ctxs[i]->b_set].folded.p, count, ncclInt32, ncclSum,
+                                      (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        return UVRT_OK;
+    }
+    // contexts of ONE device (rehearsals, tests): sum on context 0's stream, hand the result to the others
+    for (int i = 1; i < n; ++i)
+        if (ctxs[i]->device != ctxs[0]->device)
+            return fail(UVRT_ERR_INVALID, "uvrt_reduce_batch_group: contexts on different devices need uvrt_comm_init_all first");
+    uvrt_ctx* c0 = ctxs[0];
+    if (int rc = set_device(c0)) return rc;
+    for (int i = 1; i < n; ++i) {
+        HIP_TRY(hipEventRecord(ctxs[i]->ev_tail[0], ctxs[i]->stream));
+        HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev_tail[0], 0));
+        launch_add_counts(c0->bs[c0->b_set].folded.as<int32_t>(), ctxs[i]->bs[ctxs[i]->b_set].folded.as<int32_t>(), (int64_t)count, c0->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    for (int i = 1; i < n; ++i)
+        HIP_TRY(hipMemcpyAsync(ctxs[i]->bs[ctxs[i]->b_set].folded.p, c0->bs[c0->b_set].folded.p, count * 4, hipMemcpyDeviceToDevice, c0->stream));
+    HIP_TRY(hipEventRecord(c0->ev_tail[0], c0->stream));
+    for (int i = 1; i < n; ++i) {
+        HIP_TRY(hipStreamWaitEvent(ctxs[i]->stream, c0->ev_tail[0], 0));
+    }
+    return UVRT_OK;
+}
+
+}  // extern "C"

@@ -250,7 +250,9 @@ void launch_prepare_launch4(const QuadRec* quads, void* recs4, float ox, float o
 // hot-record statistics (uvrt_hotset.hip)
 void launch_visit_stats(const SceneDev& scene, uint32_t* hist, const float lamp[3], float light_length, uint32_t seed_prev,
                         uint32_t seed_next, int32_t seed_mode, int32_t n, hipStream_t s);
-void launch_select_hot(uint32_t* hist, uint32_t* perm, int32_t npairs, int32_t keep, hipStream_t s);
+// hot_list: [TOP6_MAX + 1] scratch (count + ascending indices); writes perm[0, npairs) and zeroes hist again
+void launch_select_hot(const PairRec* pairs, uint32_t* hist, uint32_t* hot_list, uint32_t* perm, int32_t npairs, int32_t keep,
+                       hipStream_t s);
 void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, int32_t T, hipStream_t s);
 constexpr uint64_t OVF_MAX_ENTRIES = (uint64_t)256 * 16 * 256 * 24;   // largest grid x deepest overflow
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,

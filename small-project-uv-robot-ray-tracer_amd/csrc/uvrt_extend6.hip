@@ -788,7 +788,7 @@ void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, in
                        (float4*)recs, npairs, T);
 }
 
-// code: bits 0-1 leaf period - 1 (0..3), bit 2 = WITHOUT the top-of-tree cache
+// code: bits 0-1 leaf period - 1 (0..3), bit 2 = WITHOUT the top-of-tree cache (codes other than 1: developer build only)
 bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream_t s)
 {
     if (p0.n <= 0) return true;
@@ -820,6 +820,7 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
         if (p.flavour) { if (p.hits) UVRT_L6K(LP, true, TOP, true); else UVRT_L6K(LP, false, TOP, true); }   \
         else { if (p.hits) UVRT_L6K(LP, true, TOP, false); else UVRT_L6K(LP, false, TOP, false); }          \
     } while (0)
+#ifdef UVRT_DEV_VARIANTS     // developer build (make dev -> libuvrt_hip_dev.so): every leaf period, with / without the LDS cache
     switch (code & 7) {
         case 0: UVRT_L6(1, true); break;
         case 1: UVRT_L6(2, true); break;
@@ -830,6 +831,10 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
         case 6: UVRT_L6(3, false); break;
         default: UVRT_L6(4, false); break;
     }
+#else                        // the product: the default kernel only (leaf visits every second trip, LDS cache)
+    if ((code & 7) != 1) return false;
+    UVRT_L6(2, true);
+#endif
 #undef UVRT_L6K
 #undef UVRT_L6
     return true;

@@ -3,17 +3,32 @@
 // The traversal kernel (uvrt_extend6.hip) serves the first records of its numbering from LDS.  Which
 // records are hot depends on the lamp: the 127 most visited ones take 62-70 % of all inner-node visits on
 // the test room (the cache holds 175), the first 127 in breadth-first order 31-40 % (profiles/r02_record_layout_experiment.txt).
-// For every new lamp position the context therefore
-//   1. traces a sample of the launch's own photons (global ids [0, S)) with k_visit_stats -- a plain
-//      one-ray-per-lane closest-hit traversal in fast arithmetic that only COUNTS inner-node visits, and
-//   2. builds the renumbering with k_select_hot: the K most visited records first (ties by index), the rest
-//      behind them in their old order.
+// For every new lamp position the context therefore enqueues three small kernels on the launch's stream:
+//   1. k_visit_stats -- traces a sample of the launch's own photons (global ids [0, S)): a plain
+//      one-ray-per-lane closest-hit traversal in fast arithmetic that only COUNTS inner-node visits.  The
+//      counters of the top of the tree (breadth-first indices < HS_LDS_BINS, where every ray of a workgroup
+//      meets) are privatised in LDS and flushed once per workgroup; the traversal stack lives in LDS too.
+//      (Round 2 counted every visit with a global atomic: 32 768 same-address atomics on the root's counter
+//      alone made the kernel 2.2 ms long -- longer than a whole 8-wave step.)
+//   2. k_select_hot -- ONE workgroup, work independent of the scene size: a ray visits a node only after
+//      its parent, so count(child) <= count(parent) and the most visited records form a subtree that
+//      contains the root.  The kernel grows that subtree level by level from the root (children whose count
+//      reaches a floor join the candidates, at most HS_CAND of them), finds the count threshold of the K-th
+//      largest by bisection over the candidates, breaks ties at the threshold by index and writes the hot
+//      records' indices in ascending order.
+//   3. k_write_perm -- the renumbering for all records (one thread per record, binary search in the hot
+//      list): the hot records first (in index order among themselves), all others behind them in index order;
+//      the visit counters are zeroed again for the next lamp.
 // Only the ORDER of records in memory follows from these statistics; every result of the traversal proper is
 // independent of it (a child reference is translated together with the records, uvrt_device.h
 // prepare_record6), so nothing here has to be exact and nothing is synchronised with the host.
 #include "uvrt_device.h"
 
 namespace uvrt {
+
+constexpr int HS_LDS_BINS = 4096;     // visit counters kept in LDS by k_visit_stats (the first 12 tree levels)
+constexpr int HS_CAND = 4096;         // candidate records of k_select_hot
+constexpr int HS_EQ = 1024;           // candidates AT the threshold that take part in the tie-break by index
 
 struct StatParams {
     const PairRec* pairs;
@@ -40,8 +55,13 @@ __device__ __forceinline__ bool box_approx(float mnx, float mny, float mnz, floa
 
 __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
 {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= p.n || p.root_ref >= REF_LEAF_BIT) return;
+    __shared__ uint32_t s_hist[HS_LDS_BINS];      // 16 KB
+    __shared__ uint32_t s_stack[32][256];         // 32 KB: entry e of thread t at [e][t] (conflict-free)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HS_LDS_BINS; i += 256) s_hist[i] = 0u;
+    __syncthreads();
+    const int gid = blockIdx.x * 256 + tid;
+    uint32_t cur = (gid < p.n && p.root_ref < REF_LEAF_BIT) ? p.root_ref : REF_DONE;
     float r0;
     double sx, sy;
     const float4 ray = generate_ray(p.lx, p.ly, p.lz, p.light_length, gid, p.seed_prev, p.seed_next, p.seed_mode, r0, sx, sy);
@@ -49,10 +69,8 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     const float dx = ray.x, dy = ray.y, dz = ray.z;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     float dist = 1e30f;
-    uint32_t stack[32];
     int sp = 0;
-    uint32_t cur = p.root_ref;
-    for (;;) {
+    while (cur != REF_DONE) {
         if (cur >= REF_LEAF_BIT) {
             const uint32_t first = cur & REF_FIRST_MASK;
             uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
@@ -72,11 +90,11 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
                 const float tt = f * (t.e2.x * qx + t.e2.y * qy + t.e2.z * qz);
                 if (tt > 0.0001f && tt < dist) dist = tt;
             }
-            if (sp == 0) return;
-            cur = stack[--sp];
+            cur = sp > 0 ? s_stack[--sp][tid] : REF_DONE;
             continue;
         }
-        atomicAdd(&p.hist[cur], 1u);
+        if (cur < (uint32_t)HS_LDS_BINS) atomicAdd(&s_hist[cur], 1u);
+        else atomicAdd(&p.hist[cur], 1u);
         const PairRec pr = p.pairs[cur];
         float d0, d1;
         const bool h0 = box_approx(pr.c0min_ref0.x, pr.c0min_ref0.y, pr.c0min_ref0.z, pr.c0max_ref1.x, pr.c0max_ref1.y,
@@ -86,88 +104,131 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
         const uint32_t r0r = __float_as_uint(pr.c0min_ref0.w), r1r = __float_as_uint(pr.c0max_ref1.w);
         if (h0 && h1) {
             const bool sw = d0 > d1;
-            if (sp < 32) stack[sp++] = sw ? r0r : r1r;
+            if (sp < 32) s_stack[sp++][tid] = sw ? r0r : r1r;
             cur = sw ? r1r : r0r;
         } else if (h0 || h1) {
             cur = h0 ? r0r : r1r;
         } else {
-            if (sp == 0) return;
-            cur = stack[--sp];
+            cur = sp > 0 ? s_stack[--sp][tid] : REF_DONE;
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < HS_LDS_BINS; i += 256) {
+        const uint32_t v = s_hist[i];
+        if (v) atomicAdd(&p.hist[i], v);          // only bins below npairs are ever counted
     }
 }
 
-// perm[i] = new index of record i: the `keep` most visited records first (in index order among themselves,
-// ties at the threshold broken by index), all others behind them in index order.  One workgroup.
-__global__ __launch_bounds__(1024) void k_select_hot(uint32_t* __restrict__ hist, uint32_t* __restrict__ perm, int32_t n,
-                                                     int32_t keep)
+// sum of `v` over the workgroup (1024 threads); `acc` is a word of LDS that nobody else touches meanwhile
+__device__ __forceinline__ uint32_t hs_block_sum(uint32_t v, uint32_t* acc)
 {
-    __shared__ uint32_t s_cnt[1024];
-    __shared__ uint32_t s_lo, s_hi;
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if (threadIdx.x == 0) *acc = 0u;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(acc, v);
+    __syncthreads();
+    return *acc;
+}
+
+// hot[0] = H (number of hot records, <= keep), hot[1 .. H] = their indices in ascending order.  One workgroup.
+__global__ __launch_bounds__(1024) void k_select_hot(const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hist,
+                                                     uint32_t* __restrict__ hot, int32_t keep)
+{
+    __shared__ uint32_t c_idx[HS_CAND], c_cnt[HS_CAND];
+    __shared__ uint32_t e_idx[HS_EQ];                 // candidates at the threshold
+    __shared__ uint32_t h_idx[TOP6_MAX + 1];          // the hot records, unordered
+    __shared__ uint32_t s_n, s_begin, s_end, s_acc, s_ne, s_nh;
     const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = tid * per, e = min(n, b + per);
-    auto block_sum = [&](uint32_t v) -> uint32_t {      // inclusive scan in s_cnt, returns the total
-        s_cnt[tid] = v;
+    const uint32_t root_cnt = hist[0];                // every sampled ray visits the root (pair record 0)
+    // the floor a record's count must reach to become a candidate; lowered if it leaves fewer than `keep`
+    uint32_t floor_cnt = root_cnt >> 6;
+    if (floor_cnt < 1u) floor_cnt = 1u;
+    uint32_t M;
+    for (;;) {
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const uint32_t t = tid >= off ? s_cnt[tid - off] : 0u;
+        if (tid == 0) { c_idx[0] = 0u; c_cnt[0] = root_cnt; s_n = 1u; s_begin = 0u; s_end = 1u; }
+        __syncthreads();
+        for (;;) {                                    // one tree level of the hot subtree per round
+            const uint32_t b = s_begin, e = s_end;
+            if (b >= e) break;
+            for (uint32_t j = b + tid; j < e; j += 1024u) {
+                const PairRec* pr = pairs + c_idx[j];
+                const uint32_t r[2] = {__float_as_uint(pr->c0min_ref0.w), __float_as_uint(pr->c0max_ref1.w)};
+                for (int k = 0; k < 2; ++k) {
+                    if (r[k] >= REF_LEAF_BIT) continue;
+                    const uint32_t c = hist[r[k]];
+                    if (c < floor_cnt) continue;
+                    const uint32_t slot = atomicAdd(&s_n, 1u);
+                    if (slot < (uint32_t)HS_CAND) { c_idx[slot] = r[k]; c_cnt[slot] = c; }
+                }
+            }
             __syncthreads();
-            s_cnt[tid] += t;
+            if (tid == 0) { s_begin = e; s_end = s_n < (uint32_t)HS_CAND ? s_n : (uint32_t)HS_CAND; s_n = s_end; }
             __syncthreads();
         }
-        return s_cnt[1023];
-    };
+        M = s_end;
+        if (M >= (uint32_t)keep || floor_cnt == 1u) break;
+        floor_cnt = floor_cnt > 8u ? floor_cnt >> 3 : 1u;
+    }
     // the smallest threshold t with #(count > t) <= keep, by bisection over the count values
-    if (tid == 0) { s_lo = 0u; s_hi = 0xFFFFFFFFu; }
-    __syncthreads();
-    for (int it = 0; it < 32; ++it) {
-        const uint32_t lo = s_lo, hi = s_hi;
-        if (lo >= hi) break;
-        const uint32_t mid = lo + (hi - lo) / 2;
-        uint32_t c = 0;
-        for (int i = b; i < e; ++i) c += hist[i] > mid;
-        const uint32_t above = block_sum(c);
-        if (tid == 0) { if ((int32_t)min(above, 0x7FFFFFFFu) <= keep) s_hi = mid; else s_lo = mid + 1; }
-        __syncthreads();
+    uint32_t lo = 0u, hi = root_cnt;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        uint32_t c = 0u;
+        for (uint32_t j = tid; j < M; j += 1024u) c += c_cnt[j] > mid;
+        const uint32_t above = hs_block_sum(c, &s_acc);
+        if (above <= (uint32_t)keep) hi = mid; else lo = mid + 1u;
     }
-    const uint32_t thr = s_lo;
-    // records above the threshold are hot; those equal to it fill what is left, lowest index first
-    uint32_t c_above = 0, c_equal = 0;
-    for (int i = b; i < e; ++i) { c_above += hist[i] > thr; c_equal += hist[i] == thr; }
-    const uint32_t tot_above = block_sum(c_above);
-    const uint32_t pre_above = s_cnt[tid] - c_above;
+    const uint32_t thr = lo;
     __syncthreads();
-    (void)block_sum(c_equal);
-    const uint32_t pre_equal = s_cnt[tid] - c_equal;
+    if (tid == 0) { s_ne = 0u; s_nh = 0u; }
     __syncthreads();
-    const uint32_t room = (uint32_t)keep > tot_above ? (uint32_t)keep - tot_above : 0u;   // ties admitted
-    // hot rank = (#hot with a smaller index); cold rank likewise: two more prefix sums over the final flags
-    uint32_t c_hot = 0;
-    {
-        uint32_t eq = pre_equal;
-        for (int i = b; i < e; ++i) {
-            const uint32_t h = hist[i];
-            c_hot += (h > thr) || (h == thr && eq < room);
-            eq += h == thr;
-        }
+    for (uint32_t j = tid; j < M; j += 1024u) {
+        const uint32_t c = c_cnt[j];
+        if (c > thr) h_idx[atomicAdd(&s_nh, 1u)] = c_idx[j];            // at most `keep` of them
+        else if (c == thr) { const uint32_t s = atomicAdd(&s_ne, 1u); if (s < (uint32_t)HS_EQ) e_idx[s] = c_idx[j]; }
     }
-    const uint32_t tot_hot = block_sum(c_hot);
-    uint32_t hot_before = s_cnt[tid] - c_hot;
     __syncthreads();
-    {
-        uint32_t eq = pre_equal;
-        uint32_t cold_before = (uint32_t)b - hot_before;
-        for (int i = b; i < e; ++i) {
-            const uint32_t h = hist[i];
-            const bool hot = (h > thr) || (h == thr && eq < room);
-            eq += h == thr;
-            perm[i] = hot ? hot_before++ : tot_hot + cold_before++;
-        }
+    const uint32_t n_above = s_nh;
+    const uint32_t n_eq = s_ne < (uint32_t)HS_EQ ? s_ne : (uint32_t)HS_EQ;
+    const uint32_t room = (uint32_t)keep - n_above;                     // ties admitted, lowest index first
+    for (uint32_t j = tid; j < n_eq; j += 1024u) {
+        const uint32_t mine = e_idx[j];
+        uint32_t before = 0u;
+        for (uint32_t k = 0; k < n_eq; ++k) before += e_idx[k] < mine;
+        if (before < room) h_idx[n_above + before] = mine;
     }
-    (void)pre_above;
     __syncthreads();
-    for (int i = b; i < e; ++i) hist[i] = 0u;          // ready for the next lamp
+    const uint32_t H = n_above + (n_eq < room ? n_eq : room);
+    for (uint32_t j = tid; j < H; j += 1024u) {
+        const uint32_t mine = h_idx[j];
+        uint32_t before = 0u;
+        for (uint32_t k = 0; k < H; ++k) before += h_idx[k] < mine;
+        hot[1u + before] = mine;
+    }
+    if (tid == 0) hot[0] = H;
+}
+
+// perm[i] = new index of record i: the hot records first (in index order among themselves), all others behind
+// them in index order; the visit counters zeroed for the next lamp.
+__global__ __launch_bounds__(256) void k_write_perm(const uint32_t* __restrict__ hot, uint32_t* __restrict__ perm,
+                                                    uint32_t* __restrict__ hist, int32_t n)
+{
+    __shared__ uint32_t s_hot[TOP6_MAX + 1];
+    const uint32_t H = hot[0] <= TOP6_MAX ? hot[0] : TOP6_MAX;
+    for (uint32_t j = threadIdx.x; j < H; j += 256u) s_hot[j] = hot[1u + j];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = 0u, hi = H;                          // hot records with an index below i
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_hot[mid] < (uint32_t)i) lo = mid + 1u; else hi = mid;
+    }
+    const bool is_hot = lo < H && s_hot[lo] == (uint32_t)i;
+    perm[i] = is_hot ? lo : H + ((uint32_t)i - lo);
+    hist[i] = 0u;
 }
 
 void launch_visit_stats(const SceneDev& scene, uint32_t* hist, const float lamp[3], float light_length, uint32_t seed_prev,
@@ -189,10 +250,14 @@ void launch_visit_stats(const SceneDev& scene, uint32_t* hist, const float lamp[
     hipLaunchKernelGGL(k_visit_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
 }
 
-void launch_select_hot(uint32_t* hist, uint32_t* perm, int32_t npairs, int32_t keep, hipStream_t s)
+void launch_select_hot(const PairRec* pairs, uint32_t* hist, uint32_t* hot_list, uint32_t* perm, int32_t npairs, int32_t keep,
+                       hipStream_t s)
 {
     if (npairs <= 0) return;
-    hipLaunchKernelGGL(k_select_hot, dim3(1), dim3(1024), 0, s, hist, perm, npairs, keep);
+    if (keep > (int32_t)TOP6_MAX) keep = (int32_t)TOP6_MAX;
+    hipLaunchKernelGGL(k_select_hot, dim3(1), dim3(1024), 0, s, pairs, (const uint32_t*)hist, hot_list, keep);
+    hipLaunchKernelGGL(k_write_perm, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, (const uint32_t*)hot_list, perm,
+                       hist, npairs);
 }
 
 }  // namespace uvrt

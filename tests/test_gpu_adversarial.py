@@ -13,27 +13,31 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def run_both(pkg, orc, tris, nodes, idx, rays, variants=(0, 401, 405, 500, 801)):
+def run_both(pkg, orc, tris, nodes, idx, rays, variants=(0, 401, 501, 801, 405, 500)):
     o_rays = rays.copy()
     o_rays["dist"] = np.float32(1e30)
     o_rays["triID"] = 0
     temp = np.zeros(tris.shape[0], dtype=np.int32)
     st = orc.extend(temp, tris, o_rays, nodes, idx)
-    c = pkg.capi.Ctx(0)
-    c.set_scene(tris, nodes, idx)
-    c.resize_rays(rays.size)
-    c.set_record_hits(True)
-    for v in variants:
-        c.set_variant(v)
-        c.reset(False)
-        c.write_rays(rays)
-        c.extend(rays.size)
-        c.sync()
-        got = c.read_rays(0, rays.size)
-        assert np.array_equal(bits(got["dist"]), bits(o_rays["dist"])), "variant %d" % v
-        assert np.array_equal(got["triID"], o_rays["triID"]), "variant %d" % v
-        assert np.array_equal(c.read_counts(), temp), "variant %d" % v
-    c.close()
+    for dev in (False, True):       # the product library, then the developer build's extra kernel variants
+        vs = [v for v in variants if pkg.capi.needs_dev(v) == dev]
+        if not vs:
+            continue
+        c = pkg.capi.Ctx(0, dev=dev)
+        c.set_scene(tris, nodes, idx)
+        c.resize_rays(rays.size)
+        c.set_record_hits(True)
+        for v in vs:
+            c.set_variant(v)
+            c.reset(False)
+            c.write_rays(rays)
+            c.extend(rays.size)
+            c.sync()
+            got = c.read_rays(0, rays.size)
+            assert np.array_equal(bits(got["dist"]), bits(o_rays["dist"])), "variant %d" % v
+            assert np.array_equal(got["triID"], o_rays["triID"]), "variant %d" % v
+            assert np.array_equal(c.read_counts(), temp), "variant %d" % v
+        c.close()
     return st, o_rays
 
 

@@ -318,3 +318,46 @@ def test_batches_and_single_launches_interleave_on_one_context(pkg, orc, oscene,
     finally:
         a.close()
         b.close()
+
+
+def test_group_collective_rejects_what_it_cannot_reduce(pkg, orc, oscene, oroute):
+    """uvrt_comm_init_all / uvrt_reduce_batch_group argument checks on real contexts: RCCL wants one rank per device
+    (two contexts of one device are refused -- uvrt_reduce_batch_group sums those without it), a group needs batches
+    of one shape, a context takes one communicator, and uvrt_reduce_batch needs a communicator and a batch."""
+    lamps = [lamp_pos(orc, oscene, oroute, k) for k in (0, 1, 2)]
+    n = 20000
+    a = pkg.capi.Ctx(0)
+    b = pkg.capi.Ctx(0)
+    try:
+        for c in (a, b):
+            c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+            c.reset(True)
+        with pytest.raises(pkg.capi.UvrtError, match="share device"):
+            pkg.capi.comm_init_all([a, b])
+        with pytest.raises(pkg.capi.UvrtError, match="no traced batch"):
+            a.reduce_batch()
+        with pytest.raises(pkg.capi.UvrtError, match="no batch of the same shape"):
+            pkg.capi.reduce_batch_group([a, b])
+        a.trace_batch(lamps[:2], 1.0, 0, n)
+        with pytest.raises(pkg.capi.UvrtError, match="no communicator"):
+            a.reduce_batch()
+        with pytest.raises(pkg.capi.UvrtError, match="no batch of the same shape"):
+            pkg.capi.reduce_batch_group([a, b])          # b holds none
+        b.trace_batch(lamps, 1.0, 0, n)
+        with pytest.raises(pkg.capi.UvrtError, match="no batch of the same shape"):
+            pkg.capi.reduce_batch_group([a, b])          # 2 launches against 3
+        # a single-context group with a communicator: the grouped RCCL branch (ncclGroupStart / AllReduce / GroupEnd)
+        pkg.capi.comm_init_all([a])
+        with pytest.raises(pkg.capi.UvrtError, match="communicator present"):
+            pkg.capi.comm_init_all([a])
+        with pytest.raises(pkg.capi.UvrtError, match="already has a communicator"):
+            a.comm_init_rank(pkg.capi.comm_unique_id(), 0, 1)
+        want = [a.read_batch_counts(k) for k in range(2)]
+        pkg.capi.reduce_batch_group([a])
+        a.reduce_batch()
+        for k in range(2):
+            assert np.array_equal(a.read_batch_counts(k), want[k])
+        a.comm_destroy()
+    finally:
+        a.close()
+        b.close()

@@ -117,17 +117,17 @@ def test_deep_stack_uses_overflow_and_matches_oracle(pkg, orc, depth):
     """Stack depths up to the reference's 32 entries (extend.cl:43): entries beyond the LDS part
     (16 in the default kernel, 8 in the staged one) live in the global overflow buffer."""
     tris, nodes, idx = chain_scene(depth, orc)
-    c = pkg.capi.Ctx(0)
-    c.set_scene(tris, nodes, idx)
     n = 65536
-    c.resize_rays(n)
-    c.set_record_hits(True)
     lp = (0.0, -0.5, 0.0)
     rays, _ = orc.generate(0, n, lp, 1.0, 0)
     temp = np.zeros(tris.shape[0], dtype=np.int32)
     st = orc.extend(temp, tris, rays, nodes, idx)
     assert st["max_stack"] == depth and st["hits"] > 0
-    for variant in (0, 404, 500, 411):
+    for variant in (0, 411, 501, 404, 500):
+        c = pkg.capi.Ctx(0, dev=pkg.capi.needs_dev(variant))
+        c.set_scene(tris, nodes, idx)
+        c.resize_rays(n)
+        c.set_record_hits(True)
         c.set_variant(variant)
         c.reset(False)
         c.seed = 0
@@ -137,15 +137,15 @@ def test_deep_stack_uses_overflow_and_matches_oracle(pkg, orc, depth):
         got = c.read_rays(0, n)
         assert np.array_equal(bits(got["dist"]), bits(rays["dist"])) and np.array_equal(got["triID"], rays["triID"])
         assert np.array_equal(c.read_counts(), temp)
-    c.close()
+        c.close()
 
 
 def test_stack_overflow_is_reported_not_silent(pkg, orc):
     """33 pending far children: the reference writes past its 32-entry array (extend.cl:43,76);
     here every variant raises UVRT_ERR_STACK at the next sync."""
     tris, nodes, idx = chain_scene(33, orc)
-    for variant in (0, 404, 500, 411):
-        c = pkg.capi.Ctx(0)
+    for variant in (0, 411, 501, 404, 500):
+        c = pkg.capi.Ctx(0, dev=pkg.capi.needs_dev(variant))
         c.set_scene(tris, nodes, idx)
         c.set_variant(variant)
         c.resize_rays(4096)

@@ -186,3 +186,20 @@ def test_empty_lamp_list_does_not_divide_by_zero(host):
     rt.AddLamp(); rt.AddLamp(); rt.AddLamp()
     assert rt.photonsPerLight == ((1 << 25) // 3) & ~1
     rt.close()
+
+
+def test_collective_entry_points_reject_bad_arguments_without_a_gpu(pkg):
+    """uvrt_comm_init_all / uvrt_reduce_batch_group / uvrt_comm_init_rank validate their arguments before they touch
+    HIP or RCCL (no device, no librccl needed); the shared-device and mismatched-batch refusals need real contexts
+    and live in tests/test_gpu_batch.py."""
+    L = pkg.capi.lib()
+    arr0 = (ctypes.c_void_p * 1)(None)
+    for n in (0, -1, 65):
+        assert L.uvrt_comm_init_all(arr0, n) == -1 and b"uvrt_comm_init_all" in L.uvrt_last_error()
+    assert L.uvrt_comm_init_all(None, 1) == -1
+    assert L.uvrt_comm_init_all(arr0, 1) == -1 and b"null context" in L.uvrt_last_error()
+    assert L.uvrt_reduce_batch_group(None, 1) == -1 and L.uvrt_reduce_batch_group(arr0, 0) == -1
+    assert L.uvrt_reduce_batch_group(arr0, 1) == -1 and b"holds no batch" in L.uvrt_last_error()
+    assert L.uvrt_comm_init_rank(None, None, 0, 1) == -1
+    assert L.uvrt_reduce_batch(None) == -1 and L.uvrt_comm_unique_id(None) == -1
+    assert L.uvrt_comm_destroy(None) == 0

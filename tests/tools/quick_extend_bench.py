@@ -15,7 +15,7 @@ lp = comp.lamp_world_pos(route["lamps"][0])
 n = int(os.environ.get("N", 2073600))
 variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
 sorts = [int(v) for v in os.environ.get("SORTS", "0,-1,12,15,18").split(",")]
-c = pkg.capi.Ctx(0)
+c = pkg.capi.Ctx(0, dev=any(pkg.capi.needs_dev(v) for v in variants))
 c.set_scene(s.tris, s.nodes, s.triIdx)
 c.resize_rays(n)
 c.set_flavour(int(os.environ.get("FLAVOUR", "0")))
