@@ -63,8 +63,11 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     const size_t plane_ints = (size_t)R * (size_t)c->T;
     // full planes are allocated for the context's replica count: R only shrinks the part of it that is used
     const size_t plane_alloc = (size_t)c->replicas * (size_t)c->T;
-    bool need_sync = S.rays.bytes < (size_t)count * (size_t)n_pad * 16 || S.planes.bytes < (size_t)count * plane_alloc * 4 ||
-                     S.folded.bytes < (size_t)count * (size_t)c->T * 4 || (int)c->b_recs.size() < ngroups || !S.free_ev;
+    // growing a buffer needs the device idle (hipFree / hipMalloc); new per-launch records only need the context's stream
+    // ordered after the lanes' earlier work -- no host synchronisation, so a new lamp position costs its kernels only
+    const bool need_alloc = S.rays.bytes < (size_t)count * (size_t)n_pad * 16 || S.planes.bytes < (size_t)count * plane_alloc * 4 ||
+                            S.folded.bytes < (size_t)count * (size_t)c->T * 4 || (int)c->b_recs.size() < ngroups || !S.free_ev;
+    bool recs_stale = false;
     const uint32_t* gperm[MAX_BATCH] = {};
     for (int g = 0; g < ngroups; ++g) {
         gperm[g] = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
@@ -75,10 +78,12 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
         }
         if (g >= (int)c->b_recs_key.size() || c->b_recs_key[g].perm != gperm[g] || memcmp(&c->b_recs_key[g].ox, &gx[g], 4) != 0 ||
             memcmp(&c->b_recs_key[g].oz, &gz[g], 4) != 0)
-            need_sync = true;
+            recs_stale = true;
     }
-    if (need_sync) {
+    if (need_alloc || recs_stale) {
         if (int rcj = join_all(c)) return rcj;
+    }
+    if (need_alloc) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (!S.free_ev) HIP_TRY(hipEventCreateWithFlags(&S.free_ev, hipEventDisableTiming));
         const bool grown = S.planes.bytes < (size_t)count * plane_alloc * 4 || S.folded.bytes < (size_t)count * (size_t)c->T * 4;
@@ -95,6 +100,8 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
         c->b_recs_key.resize(c->b_recs.size());
         for (int l = 1; l <= 2; ++l)
             if ((rc = c->xovf[l].ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream))) return rc;
+    }
+    if (need_alloc || recs_stale) {
         // per-launch records of the lamp columns whose array holds something else
         for (int g = 0; g < ngroups; ++g) {
             uvrt_ctx::RecsKey& key = c->b_recs_key[g];
@@ -119,8 +126,10 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             // two SIDE lanes in turn: the context's own stream carries the fold / reduce / replay of the previous batch,
             // which a chunk enqueued there would have to wait for
             c->lane = c->pipeline ? 1 + (int)(c->b_chunks++ & 1u) : 0;
-            hipStream_t ls;
-            if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }
+            // the chunk's rays depend on nothing but their buffer: generate goes to the lane BEFORE the lane waits for the
+            // context's stream (new records, a hot-record set-up), so it runs beside them
+            hipStream_t ls = stream_of(c, c->lane);
+            if (c->lane != 0) c->side_used[c->lane] = true;
             if (!lane_waited[c->lane]) {      // the set's previous occupant has been replayed (two batches back)
                 HIP_TRY(hipStreamWaitEvent(ls, S.free_ev, 0));
                 lane_waited[c->lane] = true;
@@ -139,6 +148,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                 gq.seed_prev[j] = gp.seed_prev[ph0 + j]; gq.seed_next[j] = gp.seed_next[ph0 + j];
             }
             launch_generate_batch(gq, ls);
+            if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }      // extend: after the fence
             ExtendParams p;
             memset(&p, 0, sizeof p);
             p.scene.pairs = c->pairs.as<PairRec>();
@@ -169,12 +179,12 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.recs = c->b_recs[g].p;
             p.perm = gperm[g];
             p.recs_prepared = 1;
-            p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
+            p.refill_min = variant_refill_min(c->variant);
+            p.leaf_k = variant_leaf_k(c->variant);
+            p.leaf_p = variant_leaf_p(c->variant);
             p.plane_batches = (uint32_t)(n_pad / 64);
             p.plane_n = (uint32_t)n;
             p.plane_stride = (uint32_t)plane_ints;
-            static const int per_cu[6] = {8, 4, 6, 2, 16, 7};
-            const int gcode = (c->variant / 10) % 10;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->timing) {
                 if (c->ev_used == c->ev_pool.size()) {
@@ -188,7 +198,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                 ++c->ev_used;
                 HIP_TRY(hipEventRecord(e0, ls));
             }
-            if (!launch_extend6(p, c->variant == 0 ? 1 : c->variant % 10, c->variant == 0 ? (c->pipeline ? 7 : 8) : per_cu[gcode < 6 ? gcode : 0], ls)) {
+            if (!launch_extend6(p, variant_code6(c->variant), variant_per_cu(c->variant, c->pipeline ? 7 : 8), ls)) {
                 c->lane = lane_before;
                 return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: variant %d needs a larger overflow-stack buffer", c->variant);
             }

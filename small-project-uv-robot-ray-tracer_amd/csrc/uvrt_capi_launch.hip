@@ -290,16 +290,15 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         return UVRT_OK;
     }
     if (c->variant >= 500 && c->variant < 600) p.force_exact = 1;
-    p.refill_min = c->variant == 0 ? 8 : c->variant >= 800 ? 4 : c->variant >= 700 ? 24 : c->variant >= 600 ? 8 : 16;
-    static const int per_cu[6] = {8, 4, 6, 2, 16, 7};
-    const int gcode = (c->variant / 10) % 10;
-    const int code6 = c->variant == 0 ? 1 : c->variant % 10;   // default: LDS top cache, leaf visits every 2nd trip
+    p.refill_min = variant_refill_min(c->variant);
+    p.leaf_k = variant_leaf_k(c->variant);
+    p.leaf_p = variant_leaf_p(c->variant);
     // default grid: 8 workgroups per CU on one stream (20 KB of LDS each: eight fit a CU); 7 when launches are
     // pipelined over several streams -- the free slot per CU lets the first workgroups of the next launch and the
     // small kernels around it (generate, accumulate, replay) run at once instead of queueing behind persistent waves
     // (profiles/r02_experiments.txt); with four launch lanes 4 per CU
     const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : c->cur_pipelined ? 7 : 8;
-    if (!launch_extend6(p, code6, c->variant == 0 ? per_cu_default : per_cu[gcode < 6 ? gcode : 0], ls))
+    if (!launch_extend6(p, variant_code6(c->variant), variant_per_cu(c->variant, per_cu_default), ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, ls));

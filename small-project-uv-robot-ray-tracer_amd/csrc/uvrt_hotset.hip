@@ -29,6 +29,7 @@ namespace uvrt {
 constexpr int HS_LDS_BINS = 4096;     // visit counters kept in LDS by k_visit_stats (the first 12 tree levels)
 constexpr int HS_CAND = 4096;         // candidate records of k_select_hot
 constexpr int HS_EQ = 1024;           // candidates AT the threshold that take part in the tie-break by index
+constexpr int HS_MAX_STEPS = 96;      // traversal steps of a sample ray that are counted
 
 struct StatParams {
     const PairRec* pairs;
@@ -70,46 +71,54 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     float dist = 1e30f;
     int sp = 0;
-    while (cur != REF_DONE) {
-        if (cur >= REF_LEAF_BIT) {
-            const uint32_t first = cur & REF_FIRST_MASK;
+    // One step per trip, ONE memory round trip per step: the 64 bytes at the lane's record -- a node-pair record or a
+    // leaf triangle (48 bytes; the 16 behind it are the next triangle's or the buffer's padding).  Deep records are
+    // cold by definition, so every trip of a wave waits for a miss to HBM: the kernel lasts (steps of the slowest
+    // ray) x (miss latency), and rays are cut off after HS_MAX_STEPS steps (0.1 % of the test room's rays take more;
+    // what they would still visit does not change which records are hot).
+    for (int it = 0; it < HS_MAX_STEPS && cur != REF_DONE; ++it) {
+        const bool leaf = cur >= REF_LEAF_BIT;
+        const uint32_t first = cur & REF_FIRST_MASK;
+        const float4* src = leaf ? (const float4*)(p.ltris + first) : (const float4*)(p.pairs + cur);
+        const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+        if (leaf) {
             uint32_t count = (cur >> REF_COUNT_SHIFT) & 15u;
             if (count == 15u) count = p.leaf_count[first];
-            for (uint32_t i = 0; i < count; ++i) {
+            float4 v0 = w0, e1 = w1, e2 = w2;
+            for (uint32_t i = 0;;) {
+                const float hx = dy * e2.z - dz * e2.y, hy = dz * e2.x - dx * e2.z, hz = dx * e2.y - dy * e2.x;
+                const float a = e1.x * hx + e1.y * hy + e1.z * hz;
+                if (fabsf(a) >= 0.00001f) {
+                    const float f = 1.0f / a;
+                    const float qx0 = ox - v0.x, qy0 = oy - v0.y, qz0 = oz - v0.z;
+                    const float u = f * (qx0 * hx + qy0 * hy + qz0 * hz);
+                    const float qx = qy0 * e1.z - qz0 * e1.y, qy = qz0 * e1.x - qx0 * e1.z, qz = qx0 * e1.y - qy0 * e1.x;
+                    const float v = f * (dx * qx + dy * qy + dz * qz);
+                    const float tt = f * (e2.x * qx + e2.y * qy + e2.z * qz);
+                    if (u >= 0 && u <= 1 && v >= 0 && u + v <= 1 && tt > 0.0001f && tt < dist) dist = tt;
+                }
+                if (++i >= count) break;
                 const LeafTri t = p.ltris[first + i];
-                const float hx = dy * t.e2.z - dz * t.e2.y, hy = dz * t.e2.x - dx * t.e2.z, hz = dx * t.e2.y - dy * t.e2.x;
-                const float a = t.e1.x * hx + t.e1.y * hy + t.e1.z * hz;
-                if (fabsf(a) < 0.00001f) continue;
-                const float f = 1.0f / a;
-                const float qx0 = ox - t.v0_id.x, qy0 = oy - t.v0_id.y, qz0 = oz - t.v0_id.z;
-                const float u = f * (qx0 * hx + qy0 * hy + qz0 * hz);
-                if (u < 0 || u > 1) continue;
-                const float qx = qy0 * t.e1.z - qz0 * t.e1.y, qy = qz0 * t.e1.x - qx0 * t.e1.z, qz = qx0 * t.e1.y - qy0 * t.e1.x;
-                const float v = f * (dx * qx + dy * qy + dz * qz);
-                if (v < 0 || u + v > 1) continue;
-                const float tt = f * (t.e2.x * qx + t.e2.y * qy + t.e2.z * qz);
-                if (tt > 0.0001f && tt < dist) dist = tt;
+                v0 = t.v0_id; e1 = t.e1; e2 = t.e2;
             }
             cur = sp > 0 ? s_stack[--sp][tid] : REF_DONE;
-            continue;
-        }
-        if (cur < (uint32_t)HS_LDS_BINS) atomicAdd(&s_hist[cur], 1u);
-        else atomicAdd(&p.hist[cur], 1u);
-        const PairRec pr = p.pairs[cur];
-        float d0, d1;
-        const bool h0 = box_approx(pr.c0min_ref0.x, pr.c0min_ref0.y, pr.c0min_ref0.z, pr.c0max_ref1.x, pr.c0max_ref1.y,
-                                   pr.c0max_ref1.z, ox, oy, oz, ix, iy, iz, dist, d0);
-        const bool h1 = box_approx(pr.c1min.x, pr.c1min.y, pr.c1min.z, pr.c1max.x, pr.c1max.y, pr.c1max.z, ox, oy, oz,
-                                   ix, iy, iz, dist, d1);
-        const uint32_t r0r = __float_as_uint(pr.c0min_ref0.w), r1r = __float_as_uint(pr.c0max_ref1.w);
-        if (h0 && h1) {
-            const bool sw = d0 > d1;
-            if (sp < 32) s_stack[sp++][tid] = sw ? r0r : r1r;
-            cur = sw ? r1r : r0r;
-        } else if (h0 || h1) {
-            cur = h0 ? r0r : r1r;
         } else {
-            cur = sp > 0 ? s_stack[--sp][tid] : REF_DONE;
+            if (cur < (uint32_t)HS_LDS_BINS) atomicAdd(&s_hist[cur], 1u);
+            else atomicAdd(&p.hist[cur], 1u);
+            // PairRec: w0 = child 0 min + ref0, w1 = child 0 max + ref1, w2 = child 1 min, w3 = child 1 max
+            float d0, d1;
+            const bool h0 = box_approx(w0.x, w0.y, w0.z, w1.x, w1.y, w1.z, ox, oy, oz, ix, iy, iz, dist, d0);
+            const bool h1 = box_approx(w2.x, w2.y, w2.z, w3.x, w3.y, w3.z, ox, oy, oz, ix, iy, iz, dist, d1);
+            const uint32_t r0r = __float_as_uint(w0.w), r1r = __float_as_uint(w1.w);
+            if (h0 && h1) {
+                const bool sw = d0 > d1;
+                if (sp < 32) s_stack[sp++][tid] = sw ? r0r : r1r;
+                cur = sw ? r1r : r0r;
+            } else if (h0 || h1) {
+                cur = h0 ? r0r : r1r;
+            } else {
+                cur = sp > 0 ? s_stack[--sp][tid] : REF_DONE;
+            }
         }
     }
     __syncthreads();

@@ -1,0 +1,109 @@
+"""Developer probe (not the bench): interleaved A/B of extend-kernel knob settings (uvrt_set_variant) on the bench's own
+step, all in ONE process -- rounds x variants, each cell = STEPS back-to-back computations bracketed by device syncs
+(cdna_hip_programming.md rule 24: perf deltas come from interleaved rounds in one process).
+
+    VARIANTS=0,1208,1308 MODE=batched STEPS=20 ROUNDS=5 python tests/tools/ab_bench.py
+
+Prints per variant the median and best Mray/s over the rounds, the dose CRC (must be the same for every variant) and,
+with ISOLATED=1, the HIP-event duration of an extend launch on one stream (launch pipelining off)."""
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+import torch  # noqa: E402  (HIP runtime order: torch first, see tests/conftest.py)
+
+torch.cuda.init()
+g.load_package()
+from uvrt_amd import host  # noqa: E402
+
+variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+mode = os.environ.get("MODE", "batched")
+steps = int(os.environ.get("STEPS", "20"))
+rounds = int(os.environ.get("ROUNDS", "5"))
+photons = int(os.environ.get("PHOTONS", str(1920 * 1080)))
+waves = int(os.environ.get("WAVES", "8"))
+nlamps = int(os.environ.get("LAMPS", "1"))
+scene = os.environ.get("SCENE", "")
+
+glb = os.path.join(ROOT, "tests", "golden", "testroomopt.glb")
+route_xml = os.path.join(ROOT, "tests", "golden", "lange_route.xml")
+if scene.startswith("soup:"):
+    sys.path.insert(0, ROOT)
+    import bench
+    mesh = host.Mesh(tris=bench.soup_triangles(int(scene[5:])))
+    rt = host.RayTracer(None, route_xml, device=0, mesh=mesh)
+else:
+    rt = host.RayTracer(glb, route_xml, device=0)
+rt.set_lamps(rt.lamps()[:nlamps])
+rt.photonCount = photons * nlamps
+rt.maxIterations = waves
+rt.ctx.set_flavour(int(os.environ.get("FLAVOUR", "0")))
+if os.environ.get("WIDE", "0") == "1":
+    rt.ctx.set_wide_bvh(True)
+rays_per_step = waves * rt.photonsPerLight * nlamps
+
+
+def step():
+    rt.ctx.seed = 0
+    rt.ResetDosageMap()
+    if mode == "batched":
+        rt.ComputeIterationsBatched(waves)
+    else:
+        for _ in range(waves):
+            rt.ComputeDosageMap()
+            rt.Shade()
+            rt.currIterations = rt.currIterations + 1
+            if mode == "loop_sync":
+                rt.Sync()
+
+
+res = {v: [] for v in variants}
+crcs = {}
+iso = {}
+for rnd in range(rounds + 1):                 # round 0 = warm-up (allocations, hot records, clocks)
+    for v in variants:
+        rt.ctx.set_variant(v)
+        step()
+        rt.Sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        rt.Sync()
+        el = time.perf_counter() - t0
+        if rnd > 0:
+            res[v].append(rays_per_step * steps / el / 1e6)
+        crcs[v] = "%08x" % zlib.crc32(rt.read_dosage().tobytes())
+if os.environ.get("ISOLATED", "0") == "1":
+    rt.ctx.set_pipeline(False)
+    for rnd in range(3):
+        for v in variants:
+            rt.ctx.set_variant(v)
+            rt.ctx.set_timing(True)
+            rt.ctx.extend_time_ms()
+            rt.ctx.seed = 0
+            rt.ResetDosageMap()
+            for _ in range(waves):
+                rt.ComputeDosageMap()
+            rt.Sync()
+            ms, k = rt.ctx.extend_time_ms()
+            rt.ctx.set_timing(False)
+            iso.setdefault(v, []).append(ms / max(k, 1))
+    rt.ctx.set_pipeline(True)
+base = np.median(res[variants[0]])
+for v in variants:
+    a = np.array(res[v])
+    line = "variant %5d  %s  median %8.1f  best %8.1f  min %8.1f Mray/s  (%+.2f %% vs %d)  crc %s" % (
+        v, mode, np.median(a), a.max(), a.min(), 100.0 * (np.median(a) / base - 1.0), variants[0], crcs[v])
+    if v in iso:
+        line += "  isolated extend %.4f ms" % min(iso[v])
+    print(line, flush=True)
+if len(set(crcs.values())) != 1:
+    print("DOSE MISMATCH between variants", crcs)
+    sys.exit(1)
