@@ -198,6 +198,12 @@ def main():
     ap.add_argument("--seed-mode", type=int, default=0, choices=[0, 1],
                     help="SEED semantics of generate.cl (include/uvrt.h uvrt_set_seed_mode): 0 = canonical (SURVEY 8c), "
                          "1 = what the reference's kernel does on gfx950; with --flavour 1 the reference's live kernel chain")
+    ap.add_argument("--self-comm", action="store_true",
+                    help="N = 1 rehearsal of a rank's step of the sharded job: a one-rank RCCL communicator, so that every "
+                         "computation launches the real all-reduce kernel of the count planes (uvrt_reduce_batch) between its "
+                         "tracing and its replay; with --photons 259200 the step is a rank's share of the 8-GPU step")
+    ap.add_argument("--high-priority-stream", action="store_true",
+                    help="the context's stream (replay, collective) is created with high priority; the launch lanes keep the default")
     args = ap.parse_args()
 
     import numpy as np
@@ -266,7 +272,7 @@ def main():
     configure(headline_lamps, args.photons, args.waves)
     # One real (non-default) torch stream carries BOTH the uvrt kernels and any torch collective, so reductions
     # are ordered after the last deposit and before the replay without host syncs.
-    stream = torch.cuda.Stream(device=device)
+    stream = torch.cuda.Stream(device=device, priority=-1 if args.high_priority_stream else 0)
     assert stream.cuda_stream != 0
     rt.ctx.set_stream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
@@ -292,6 +298,11 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         rt.ctx.comm_init_rank(ids[0], rank, world)
         native_comm = True
+    if args.self_comm:
+        if world != 1 or args.mode != "batched":
+            raise SystemExit("--self-comm is the N = 1 rehearsal of the batched, sharded step")
+        rt.ctx.comm_init_rank(capi.comm_unique_id(), 0, 1)
+        rt.set_reduce_over_comm(True)
     share = (n_launch + world - 1) // world
     first = min(rank * share, n_launch)
     mine = min(share, n_launch - first)
@@ -648,7 +659,8 @@ def main():
                                    "(myapp.cpp:156-170) does not use; other_modes.loop / loop_sync are the drop-in figures"
                                    if args.mode == "batched" else "the reference's host loop (myapp.cpp:156-165)"),
                        "launch_pipelining": bool(not args.no_pipeline), "flavour": args.flavour, "seed_mode": args.seed_mode,
-                       "wide_bvh": bool(args.wide), "parallelism": par},
+                       "wide_bvh": bool(args.wide), "parallelism": par,
+                       "self_comm": bool(args.self_comm), "high_priority_stream": bool(args.high_priority_stream)},
             "roofline": roof, "cpu_baseline": cpu,
             "dose_crc32": crc_timed, "dose_crc32_expected": expected, "dose_crc32_after_all_passes": crc(dose_after),
             "value_is": "steady-state throughput of back-to-back computations (one device sync after the last step)",
@@ -673,6 +685,8 @@ def main():
         if native_comm:
             rt.ctx.comm_destroy()
         dist.destroy_process_group()
+    if args.self_comm:
+        rt.ctx.comm_destroy()
     rt.close()
 
 

@@ -68,6 +68,10 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     if (const char* e = getenv("UVRT_LANES")) { const int v = atoi(e); if (v >= 1 && v <= uvrt_ctx::MAXL) c->nlanes = v; }
     if (const char* e = getenv("UVRT_PIPELINE")) c->pipeline = atoi(e) != 0;   // developer knob
     if (const char* e = getenv("UVRT_BATCH_CHUNK_MB")) { const long v = atol(e); if (v > 0) c->batch_chunk_bytes = (size_t)v << 20; }
+#ifdef UVRT_DEV_VARIANTS
+    if (const char* e = getenv("UVRT_PROBE_SKIP_GENERATE")) c->probe_skip_generate = atoi(e);
+#endif
+    if (const char* e = getenv("UVRT_COMM_RESERVE_CUS")) { const int v = atoi(e); if (v >= 0 && v <= 64 && v % 8 == 0) c->comm_reserve_knob = v; }
     if (const char* e = getenv("UVRT_HOT_SAMPLE")) { const int v = atoi(e); if (v >= 256 && v <= (1 << 20)) c->hot_sample = v; }
     int rc = c->error_flag.ensure(256, true, c->stream);      // the flag; a developer build keeps trip statistics behind it
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
@@ -82,6 +86,7 @@ void uvrt_destroy(uvrt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) uvrt_comm_destroy(c);       // first: it restores the lanes' plain streams
     for (int l = 0; l < uvrt_ctx::MAXL; ++l) {
         if (c->side[l]) (void)hipStreamSynchronize(c->side[l]);
         for (DevBuf* b : {&c->xrays[l], &c->xrecs[l], &c->xcounts[l], &c->xovf[l]}) b->release();
@@ -90,7 +95,6 @@ void uvrt_destroy(uvrt_ctx* c)
     }
     if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
     if (c->ev_mapfence) (void)hipEventDestroy(c->ev_mapfence);
-    if (c->comm) uvrt_comm_destroy(c);
     c->quads.release();
     for (DevBuf& b : c->recs4) b.release();
     for (DevBuf& b : c->b_recs) b.release();

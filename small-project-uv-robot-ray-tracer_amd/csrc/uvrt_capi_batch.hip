@@ -147,6 +147,9 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                 gq.lx[j] = gp.lx[ph0 + j]; gq.ly[j] = gp.ly[ph0 + j]; gq.lz[j] = gp.lz[ph0 + j];
                 gq.seed_prev[j] = gp.seed_prev[ph0 + j]; gq.seed_next[j] = gp.seed_next[ph0 + j];
             }
+#ifdef UVRT_DEV_VARIANTS
+            if (!(c->probe_skip_generate > 0 && c->probe_batches >= c->probe_skip_generate))
+#endif
             launch_generate_batch(gq, ls);
             if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }      // extend: after the fence
             ExtendParams p;
@@ -165,7 +168,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             }
             p.ovf_stack = lane_ovf(c).as<uint32_t>();
             p.ovf_capacity = lane_ovf(c).bytes / sizeof(uint32_t);
-            p.num_cus = c->num_cus;
+            p.num_cus = lane_cus(c);
             p.flavour = c->flavour;
             p.top_pairs = c->top_pairs;
             p.counts = S.planes.as<int32_t>() + (size_t)ph0 * plane_ints;
@@ -182,6 +185,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.refill_min = variant_refill_min(c->variant);
             p.leaf_k = variant_leaf_k(c->variant);
             p.leaf_p = variant_leaf_p(c->variant);
+            p.touch_pushed = variant_touch_pushed(c->variant, (size_t)c->npairs + (size_t)c->T);
             p.plane_batches = (uint32_t)(n_pad / 64);
             p.plane_n = (uint32_t)n;
             p.plane_stride = (uint32_t)plane_ints;
@@ -206,6 +210,9 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             if (c->timing) HIP_TRY(hipEventRecord(e1, ls));
         }
     }
+#ifdef UVRT_DEV_VARIANTS
+    ++c->probe_batches;
+#endif
     c->lane = 0;
     c->cur_pipelined = false;
     c->last_n = -1;                      // the per-launch generate/extend pairing starts afresh

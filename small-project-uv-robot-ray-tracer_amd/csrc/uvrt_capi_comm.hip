@@ -48,6 +48,46 @@ int rccl_load()
     g_rccl.lib = h;
     return UVRT_OK;
 }
+}  // namespace
+
+namespace uvrt_impl {
+
+// RCCL's device kernels on gfx950 (ncclDevKernel_Generic_*, librccl 2.x of ROCm 7.2: read off the code object's kernel
+// descriptors) take 37 664 B of LDS and 248-256 VGPRs per wave in workgroups of up to 512 threads: such a workgroup
+// cannot become resident on a CU that holds more than four of k_extend6's (20 KB of LDS, 64 VGPRs), and the persistent
+// tracing grid holds seven on EVERY CU until its launch drains -- the all-reduce of batch k would wait for the trace of
+// batch k + 1 to end instead of running beside it.  So while a communicator is set, the launch lanes' streams are created
+// with a CU mask (hipExtStreamCreateWithCUMask) that leaves `reserve` CUs to the context's stream, where the fold, the
+// collective and the replay run.  On the MI355X mask bit b is XCC b % 8 (tests/tools/cumask_probe.hip,
+// profiles/r03_cumask_probe.txt): clearing the LAST eight bits takes one CU from every XCD, so the round-robin deal of
+// workgroups to XCDs stays balanced.
+int set_lane_cu_mask(uvrt_ctx* c, int reserve)
+{
+    if (reserve < 0 || reserve % 8 != 0 || reserve >= c->num_cus) reserve = 0;
+    if (reserve == c->lanes_masked_cus) return UVRT_OK;
+    if (int rc = set_device(c)) return rc;
+    if (int rc = join_all(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t words = (uint32_t)((c->num_cus + 31) / 32);
+    std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+    for (int k = 0; k < reserve; ++k) { const int bit = c->num_cus - 1 - k; mask[bit / 32] &= ~(1u << (bit % 32)); }
+    for (int l = 1; l < uvrt_ctx::MAXL; ++l) {
+        hipStream_t fresh = nullptr;
+        if (reserve > 0) HIP_TRY(hipExtStreamCreateWithCUMask(&fresh, words, mask.data()));
+        else HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+        if (c->side[l]) { HIP_TRY(hipStreamSynchronize(c->side[l])); HIP_TRY(hipStreamDestroy(c->side[l])); }
+        c->side[l] = fresh;
+        c->side_used[l] = false;
+        c->side_seen_fence[l] = 0;            // the new stream has seen no fence: it waits for the current ones at first use
+        c->side_seen_mapfence[l] = 0;
+    }
+    c->lanes_masked_cus = reserve;
+    return UVRT_OK;
+}
+
+}  // namespace uvrt_impl
+
+namespace {
 #define RCCL_TRY(expr)                                                                         \
     do {                                                                                        \
         ncclResult_t r_ = (expr);                                                               \
@@ -80,7 +120,7 @@ int uvrt_comm_init_rank(uvrt_ctx* c, const void* id128, int32_t rank, int32_t wo
     c->comm = comm;
     c->comm_rank = rank;
     c->comm_world = world;
-    return UVRT_OK;
+    return set_lane_cu_mask(c, c->comm_reserve_knob);
 }
 
 int uvrt_comm_init_all(uvrt_ctx** ctxs, int32_t n)
@@ -99,6 +139,8 @@ int uvrt_comm_init_all(uvrt_ctx** ctxs, int32_t n)
     ncclComm_t comms[64];
     RCCL_TRY(g_rccl.CommInitAll(comms, n, devs));
     for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_rank = i; ctxs[i]->comm_world = n; }
+    for (int i = 0; i < n; ++i)
+        if (int rc = set_lane_cu_mask(ctxs[i], ctxs[i]->comm_reserve_knob)) return rc;
     return UVRT_OK;
 }
 
@@ -113,7 +155,7 @@ int uvrt_comm_destroy(uvrt_ctx* c)
     c->comm = nullptr;
     c->comm_world = 1;
     c->comm_rank = 0;
-    return UVRT_OK;
+    return set_lane_cu_mask(c, 0);
 }
 
 int uvrt_reduce_batch(uvrt_ctx* c)

@@ -232,7 +232,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.hits = c->record_hits ? c->hits.as<uint2>() : nullptr;
     p.ovf_stack = lane_ovf(c).as<uint32_t>();
     p.ovf_capacity = lane_ovf(c).bytes / sizeof(uint32_t);
-    p.num_cus = c->num_cus;
+    p.num_cus = lane_cus(c);
     p.flavour = c->flavour;
     p.top_pairs = c->top_pairs;
     p.counts = lane_counts(c).as<int32_t>();
@@ -293,6 +293,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.refill_min = variant_refill_min(c->variant);
     p.leaf_k = variant_leaf_k(c->variant);
     p.leaf_p = variant_leaf_p(c->variant);
+    p.touch_pushed = variant_touch_pushed(c->variant, (size_t)c->npairs + (size_t)c->T);
     // default grid: 8 workgroups per CU on one stream (20 KB of LDS each: eight fit a CU); 7 when launches are
     // pipelined over several streams -- the free slot per CU lets the first workgroups of the next launch and the
     // small kernels around it (generate, accumulate, replay) run at once instead of queueing behind persistent waves

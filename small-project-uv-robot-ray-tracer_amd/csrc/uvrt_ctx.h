@@ -155,6 +155,10 @@ struct uvrt_ctx {
     int32_t b_phys[uvrt::MAX_BATCH] = {};       // logical launch -> physical plane (launches are grouped by lamp)
     bool b_is_folded = false;             // b_folded holds the batch (fold / all-reduce done), the replicas are zero
     void* comm = nullptr;                 // ncclComm_t of a ray-range-sharded job (uvrt_comm_init_rank)
+    // CUs the launch lanes leave to the context's stream while a communicator is set (uvrt_capi_comm.hip
+    // reserve_cus_for_comm): the lanes' streams carry a CU mask, the persistent grids are sized for the rest
+    int comm_reserve_knob = 8;            // developer knob UVRT_COMM_RESERVE_CUS (a multiple of 8, 0 = none)
+    int lanes_masked_cus = 0;             // CUs masked out of the side lanes' streams right now
     int comm_rank = 0, comm_world = 1;
 
     // generate.cl:6 program-scope SEED
@@ -166,6 +170,14 @@ struct uvrt_ctx {
     bool record_hits = false;
     int32_t variant = 0;
     int32_t flavour = 0;
+#ifdef UVRT_DEV_VARIANTS
+    // timing-only probe of the developer build (UVRT_PROBE_SKIP_GENERATE=n): after n uvrt_trace_batch calls the generate
+    // launches are skipped -- the buffers still hold the same rays when every computation is the same (bench.py), so
+    // the dose stays right and the step shows what k_generate_batch costs the pipeline (an upper bound for any scheme
+    // that makes the rays elsewhere)
+    int probe_skip_generate = 0;
+    int probe_batches = 0;
+#endif
     size_t batch_chunk_bytes = (size_t)96 << 20;   // rays per fused launch of a batch (developer knob UVRT_BATCH_CHUNK_MB,
                                                    // read once in uvrt_create): a chunk's rays stay in the Infinity Cache
 
@@ -247,6 +259,8 @@ inline int order_after_previous(uvrt_ctx* c)
     c->side_used[l] = true;
     return UVRT_OK;
 }
+// compute units the persistent grid of a launch on the current lane is sized for
+inline int lane_cus(const uvrt_ctx* c) { return c->lane == 0 ? c->num_cus : c->num_cus - c->lanes_masked_cus; }
 inline DevBuf& lane_rays(uvrt_ctx* c) { return c->lane ? c->xrays[c->lane] : c->rays; }
 inline DevBuf& lane_recs(uvrt_ctx* c) { return c->lane ? c->xrecs[c->lane] : c->recs; }
 inline DevBuf& lane_counts(uvrt_ctx* c) { return c->lane ? c->xcounts[c->lane] : c->counts; }
@@ -285,10 +299,11 @@ inline void split_bits(int bits, int& bphi, int& by, int& bo)
 // and DESIGN.md section 4 for what they measured.)
 // 1000-1999 = the default kernel with another leaf-visit rule: 1000 + 100 * leaf_p + leaf_k (uvrt_extend6.hip
 // leaf_trip_rule: a lane at a leaf waits at most leaf_p trips, or until leaf_k lanes stand at one)
+// 900 / 901 = the default kernel with the touch of pushed records forced off / on (default: by the size of the scene)
 #ifdef UVRT_DEV_VARIANTS
-inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900) || (v >= 1100 && v < 2000 && v % 100 != 0); }
+inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900) || v == 900 || v == 901 || (v >= 1100 && v < 2000 && v % 100 != 0); }
 #else      // the product library holds the default kernel only: code 1 (leaf period 2, LDS cache) with any grid / refill knob
-inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900 && v % 10 == 1) || (v >= 1100 && v < 2000 && v % 100 != 0); }
+inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900 && v % 10 == 1) || v == 900 || v == 901 || (v >= 1100 && v < 2000 && v % 100 != 0); }
 #endif
 
 inline int auto_sort_bits(int64_t n)
@@ -310,6 +325,10 @@ inline int variant_per_cu(int v, int dflt)
     const int gcode = (v / 10) % 10;
     return !variant_is_knob(v) ? dflt : per_cu[gcode < 6 ? gcode : 0];
 }
+// records (64 B each) beyond which a pushed child's record is touched at the push: the XCD's 4 MiB L2 no longer holds
+// the tree (measured: profiles/r03_experiments.txt)
+constexpr size_t TOUCH_PUSHED_MIN_RECORDS = ((size_t)16 << 20) / 64;
+inline int variant_touch_pushed(int v, size_t records) { return v == 900 ? 0 : v == 901 ? 1 : records >= TOUCH_PUSHED_MIN_RECORDS ? 1 : 0; }
 constexpr int LEAF_P_DEFAULT = 2, LEAF_K_DEFAULT = 65;     // 65: never by lane count alone
 inline int variant_leaf_p(int v) { return v >= 1100 && v < 2000 ? (v - 1000) / 100 : LEAF_P_DEFAULT; }
 inline int variant_leaf_k(int v) { return v >= 1100 && v < 2000 ? (v - 1000) % 100 : LEAF_K_DEFAULT; }
@@ -321,6 +340,8 @@ int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t s
                 hipStream_t s, int lane, const uint32_t** out);
 // drops every cached renumbering (a new scene); with `slab`, the first slab of the new scene is allocated at once
 int hot_reset(uvrt_ctx* c, bool slab);
+// (re)creates the side lanes' streams with `reserve` CUs masked out, one per XCD and mask word of 8 (0: plain streams)
+int set_lane_cu_mask(uvrt_ctx* c, int reserve);
 // the scene part of an ExtendParams
 inline void fill_scene(const uvrt_ctx* c, ExtendParams& p)
 {

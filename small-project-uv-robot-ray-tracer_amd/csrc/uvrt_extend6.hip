@@ -279,6 +279,12 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
 // at least leaf_k of the wave's lanes stand at one, or leaf_p trips have passed since the last leaf visit (%[km]
 // counts them down), or no lane is left at an inner node -- the ~55 instructions of the triangle test then serve
 // several lanes instead of one or two.
+// Touch of the pushed child (p.touch_pushed, scenes whose records do not fit in L2): a node that is pushed IS visited
+// later (the reference pops and visits without another test, extend.cl:77-79), so its record is fetched for certain --
+// a one-dword load of it, past L1 (sc1), issued at the push brings the line into L2 while the nearer subtree is walked.
+// Its destination v55 is the one register of the record window nobody reads: the fourth dword of the refs quarter of a
+// pair record (zero), dead in the triangle test by then; vector-memory loads return in issue order, so the next trip's
+// record load lands after it, and the stream waits for it before it leaves.
 // Arithmetic: slabs / boxes / hit tests are step7's (slabs6, box2_fast, the v_cmpx tail); the triangle test is
 // tri6<OCL> instruction for instruction (extend.cl:6-27), early returns as v_cmpx narrowing of exec.
 // A kernel with this stream must not spill: scratch use costs the launch pipelining 14 % (measured); the general
@@ -437,6 +443,11 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "v_cndmask_b32 v63, v53, v52, %[m4]\n\t" \
         "ds_write_b32 v57, v63 offset:1024\n\t" \
         "v_add_u32 %[sp], 1, %[sp]\n\t" \
+        "s_bitcmp1_b32 %[pf], 0\n\t"                   /* scenes beyond L2: touch the pushed child's record now (below) */ \
+        "s_cbranch_scc0 6f\n\t" \
+        "v_lshlrev_b32 v59, 6, v63\n\t" \
+        "global_load_dword v55, v59, %[rb] sc1\n\t" \
+        "6:\n\t" \
         "s_or_b64 exec, %[m2], %[m1]\n\t" \
         "v_cndmask_b32 %[cur], v52, v53, %[m4]\n\t" \
         "s_andn2_b64 %[m4], %[m0], exec\n\t" \
@@ -456,14 +467,15 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "s_branch 9f\n\t" \
         "8:\n\t" \
         "s_mov_b32 %[code], 2\n\t" \
-        "9:"
+        "9:\n\t" \
+        "s_waitcnt vmcnt(0)"                             /* a touch of the last trip may still be on its way to v55 */
 
 #define R7_OPERANDS \
         : [cur] "+v"(L.cur), [sp] "+v"(L.sp), [dist] "+v"(dist), [tri] "+v"(L.triID), [km] "+s"(km), [code] "=&s"(code), [t2] "=&s"(t2), \
           [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4) \
         : [px] "v"(L.px), [py] "v"(L.py), [pz] "v"(L.pz), [po] "v"(L.po), [dx] "v"(L.px.x), [dy] "v"(L.py.x), [dz] "v"(L.pz.x), \
           [oy] "v"(oy), [sb] "v"(stack_base), [tb] "s"(__builtin_amdgcn_readfirstlane(top_base)), [full] "s"(full), [rb] "s"(p.recs), [spec] "s"(special_mask), \
-          [tp] "s"(top_pairs), [amin] "s"(active_min), [ox] "s"(p.ox), [oz] "s"(p.oz), [kk] "s"(p.leaf_k), [pp] "s"(p.leaf_p) \
+          [tp] "s"(top_pairs), [amin] "s"(active_min), [ox] "s"(p.ox), [oz] "s"(p.oz), [kk] "s"(p.leaf_k), [pp] "s"(p.leaf_p), [pf] "s"(p.touch_pushed) \
         : "memory", "scc", "vcc", R7_CLOBBERS
 
 template <bool OCL, int LEAFP>

@@ -7,15 +7,16 @@
 //   1. k_visit_stats -- traces a sample of the launch's own photons (global ids [0, S)): a plain
 //      one-ray-per-lane closest-hit traversal in fast arithmetic that only COUNTS inner-node visits.  The
 //      counters of the top of the tree (breadth-first indices < HS_LDS_BINS, where every ray of a workgroup
-//      meets) are privatised in LDS and flushed once per workgroup; the traversal stack lives in LDS too.
+//      meets) are privatised in LDS and flushed once per workgroup, visits to deeper records are queued in LDS and
+//      counted in bursts; the traversal stack lives in LDS too.
 //      (Round 2 counted every visit with a global atomic: 32 768 same-address atomics on the root's counter
 //      alone made the kernel 2.2 ms long -- longer than a whole 8-wave step.)
 //   2. k_select_hot -- ONE workgroup, work independent of the scene size: a ray visits a node only after
 //      its parent, so count(child) <= count(parent) and the most visited records form a subtree that
 //      contains the root.  The kernel grows that subtree level by level from the root (children whose count
-//      reaches a floor join the candidates, at most HS_CAND of them), finds the count threshold of the K-th
-//      largest by bisection over the candidates, breaks ties at the threshold by index and writes the hot
-//      records' indices in ascending order.
+//      reaches a floor join the candidates, at most HS_CAND of them), finds the count of the K-th largest by a
+//      radix select over the candidates, breaks ties at that count by index and writes the hot records' indices
+//      in ascending order.
 //   3. k_write_perm -- the renumbering for all records (one thread per record, binary search in the hot
 //      list): the hot records first (in index order among themselves), all others behind them in index order;
 //      the visit counters are zeroed again for the next lamp.
@@ -26,10 +27,11 @@
 
 namespace uvrt {
 
-constexpr int HS_LDS_BINS = 4096;     // visit counters kept in LDS by k_visit_stats (the first 12 tree levels)
+constexpr int HS_LDS_BINS = 8192;     // visit counters kept in LDS by k_visit_stats (the first 13 tree levels)
+constexpr int HS_QUEUE = 16;          // visits to deeper records a lane collects in LDS before the wave flushes them
 constexpr int HS_CAND = 4096;         // candidate records of k_select_hot
 constexpr int HS_EQ = 1024;           // candidates AT the threshold that take part in the tie-break by index
-constexpr int HS_MAX_STEPS = 96;      // traversal steps of a sample ray that are counted
+constexpr int HS_MAX_STEPS = 64;      // traversal steps of a sample ray that are counted (99 % of the test room's rays take fewer)
 
 struct StatParams {
     const PairRec* pairs;
@@ -56,8 +58,9 @@ __device__ __forceinline__ bool box_approx(float mnx, float mny, float mnz, floa
 
 __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
 {
-    __shared__ uint32_t s_hist[HS_LDS_BINS];      // 16 KB
+    __shared__ uint32_t s_hist[HS_LDS_BINS];      // 32 KB
     __shared__ uint32_t s_stack[32][256];         // 32 KB: entry e of thread t at [e][t] (conflict-free)
+    __shared__ uint32_t s_queue[HS_QUEUE][256];   // 16 KB: deep records visited by thread t, not yet counted
     const int tid = threadIdx.x;
     for (int i = tid; i < HS_LDS_BINS; i += 256) s_hist[i] = 0u;
     __syncthreads();
@@ -71,10 +74,19 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     float dist = 1e30f;
     int sp = 0;
+    int qn = 0;
+    // A visit to a record beyond the LDS counters is queued in LDS and counted later, HS_QUEUE visits per lane in one
+    // burst of global atomics: memory operations complete in issue order (vmcnt), so an atomic issued in every trip
+    // would put its round trip to the memory side (600-3000 cycles) in front of the next trip's record fetch.
+    auto flush_queue = [&]() {
+        for (int e = 0; e < HS_QUEUE; ++e)
+            if (e < qn) atomicAdd(&p.hist[s_queue[e][tid]], 1u);
+        qn = 0;
+    };
     // One step per trip, ONE memory round trip per step: the 64 bytes at the lane's record -- a node-pair record or a
     // leaf triangle (48 bytes; the 16 behind it are the next triangle's or the buffer's padding).  Deep records are
     // cold by definition, so every trip of a wave waits for a miss to HBM: the kernel lasts (steps of the slowest
-    // ray) x (miss latency), and rays are cut off after HS_MAX_STEPS steps (0.1 % of the test room's rays take more;
+    // ray) x (miss latency + the step's ~150 instructions at one wave per SIMD), and rays are cut off after HS_MAX_STEPS steps (1 % of the test room's rays take more;
     // what they would still visit does not change which records are hot).
     for (int it = 0; it < HS_MAX_STEPS && cur != REF_DONE; ++it) {
         const bool leaf = cur >= REF_LEAF_BIT;
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
             cur = sp > 0 ? s_stack[--sp][tid] : REF_DONE;
         } else {
             if (cur < (uint32_t)HS_LDS_BINS) atomicAdd(&s_hist[cur], 1u);
-            else atomicAdd(&p.hist[cur], 1u);
+            else s_queue[qn++][tid] = cur;
             // PairRec: w0 = child 0 min + ref0, w1 = child 0 max + ref1, w2 = child 1 min, w3 = child 1 max
             float d0, d1;
             const bool h0 = box_approx(w0.x, w0.y, w0.z, w1.x, w1.y, w1.z, ox, oy, oz, ix, iy, iz, dist, d0);
@@ -120,7 +132,9 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
                 cur = sp > 0 ? s_stack[--sp][tid] : REF_DONE;
             }
         }
+        if (__builtin_amdgcn_ballot_w64(qn >= HS_QUEUE) != 0) flush_queue();      // wave-uniform
     }
+    flush_queue();
     __syncthreads();
     for (int i = tid; i < HS_LDS_BINS; i += 256) {
         const uint32_t v = s_hist[i];
@@ -128,27 +142,18 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     }
 }
 
-// sum of `v` over the workgroup (1024 threads); `acc` is a word of LDS that nobody else touches meanwhile
-__device__ __forceinline__ uint32_t hs_block_sum(uint32_t v, uint32_t* acc)
-{
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if (threadIdx.x == 0) *acc = 0u;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(acc, v);
-    __syncthreads();
-    return *acc;
-}
-
 // hot[0] = H (number of hot records, <= keep), hot[1 .. H] = their indices in ascending order.  One workgroup.
-__global__ __launch_bounds__(1024) void k_select_hot(const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hist,
-                                                     uint32_t* __restrict__ hot, int32_t keep)
+constexpr int HS_SEL_THREADS = 256;
+__global__ __launch_bounds__(HS_SEL_THREADS) void k_select_hot(const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hist,
+                                                             uint32_t* __restrict__ hot, int32_t keep)
 {
     __shared__ uint32_t c_idx[HS_CAND], c_cnt[HS_CAND];
     __shared__ uint32_t e_idx[HS_EQ];                 // candidates at the threshold
     __shared__ uint32_t h_idx[TOP6_MAX + 1];          // the hot records, unordered
-    __shared__ uint32_t s_n, s_begin, s_end, s_acc, s_ne, s_nh;
+    __shared__ uint32_t s_bins[256], s_wsum[4];
+    __shared__ uint32_t s_n, s_begin, s_end, s_ne, s_nh, s_digit, s_above;
     const int tid = threadIdx.x;
+    constexpr uint32_t NT = HS_SEL_THREADS;
     const uint32_t root_cnt = hist[0];                // every sampled ray visits the root (pair record 0)
     // the floor a record's count must reach to become a candidate; lowered if it leaves fewer than `keep`
     uint32_t floor_cnt = root_cnt >> 6;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(1024) void k_select_hot(const PairRec* __restrict__
         for (;;) {                                    // one tree level of the hot subtree per round
             const uint32_t b = s_begin, e = s_end;
             if (b >= e) break;
-            for (uint32_t j = b + tid; j < e; j += 1024u) {
+            for (uint32_t j = b + tid; j < e; j += NT) {
                 const PairRec* pr = pairs + c_idx[j];
                 const uint32_t r[2] = {__float_as_uint(pr->c0min_ref0.w), __float_as_uint(pr->c0max_ref1.w)};
                 for (int k = 0; k < 2; ++k) {
@@ -180,29 +185,52 @@ __global__ __launch_bounds__(1024) void k_select_hot(const PairRec* __restrict__
         if (M >= (uint32_t)keep || floor_cnt == 1u) break;
         floor_cnt = floor_cnt > 8u ? floor_cnt >> 3 : 1u;
     }
-    // the smallest threshold t with #(count > t) <= keep, by bisection over the count values
-    uint32_t lo = 0u, hi = root_cnt;
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2u;
-        uint32_t c = 0u;
-        for (uint32_t j = tid; j < M; j += 1024u) c += c_cnt[j] > mid;
-        const uint32_t above = hs_block_sum(c, &s_acc);
-        if (above <= (uint32_t)keep) hi = mid; else lo = mid + 1u;
+    // The count of the keep-th largest candidate (0 when there are fewer), digit by digit: per 8-bit digit a histogram
+    // of the candidates that match the digits fixed so far, its suffix sums (bin 255 down) by a scan over the 256
+    // threads, and the bin in which `keep` candidates are reached.  Then #(count > thr) < keep.
+    uint32_t prefix = 0u, above = 0u;                 // digits fixed so far; candidates known to lie above the threshold
+    const int top_shift = root_cnt < (1u << 8) ? 0 : root_cnt < (1u << 16) ? 8 : root_cnt < (1u << 24) ? 16 : 24;
+    const uint32_t lane = (uint32_t)tid & 63u, wv = (uint32_t)tid >> 6;
+    for (int shift = top_shift; shift >= 0; shift -= 8) {
+        s_bins[tid] = 0u;                             // NT == 256 bins
+        __syncthreads();
+        const uint32_t hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t j = tid; j < M; j += NT) {
+            const uint32_t c = c_cnt[j];
+            if ((c & hi_mask) == prefix) atomicAdd(&s_bins[(c >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const uint32_t v = s_bins[255 - tid];         // thread t looks at digit 255 - t
+        uint32_t x = v;                               // inclusive scan: candidates with a digit >= 255 - t
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if ((int)lane >= off) x += y;
+        }
+        if (lane == 63u) s_wsum[wv] = x;
+        __syncthreads();
+        for (uint32_t w2 = 0; w2 < wv; ++w2) x += s_wsum[w2];
+        const uint32_t upto = above + x;              // candidates above the threshold's range or with a digit >= 255 - t
+        if ((upto >= (uint32_t)keep && upto - v < (uint32_t)keep) || (tid == 255 && upto < (uint32_t)keep)) {
+            s_digit = 255u - (uint32_t)tid;           // exactly one thread: the digit of the keep-th largest (0 if too few)
+            s_above = upto - v;
+        }
+        __syncthreads();
+        prefix |= s_digit << shift;
+        above = s_above;
     }
-    const uint32_t thr = lo;
-    __syncthreads();
+    const uint32_t thr = prefix;                      // count > thr: hot for sure (`above` of them, < keep); == thr: ties
     if (tid == 0) { s_ne = 0u; s_nh = 0u; }
     __syncthreads();
-    for (uint32_t j = tid; j < M; j += 1024u) {
+    for (uint32_t j = tid; j < M; j += NT) {
         const uint32_t c = c_cnt[j];
-        if (c > thr) h_idx[atomicAdd(&s_nh, 1u)] = c_idx[j];            // at most `keep` of them
-        else if (c == thr) { const uint32_t s = atomicAdd(&s_ne, 1u); if (s < (uint32_t)HS_EQ) e_idx[s] = c_idx[j]; }
+        if (c > thr) h_idx[atomicAdd(&s_nh, 1u)] = c_idx[j];
+        else if (c == thr) { const uint32_t q = atomicAdd(&s_ne, 1u); if (q < (uint32_t)HS_EQ) e_idx[q] = c_idx[j]; }
     }
     __syncthreads();
     const uint32_t n_above = s_nh;
     const uint32_t n_eq = s_ne < (uint32_t)HS_EQ ? s_ne : (uint32_t)HS_EQ;
     const uint32_t room = (uint32_t)keep - n_above;                     // ties admitted, lowest index first
-    for (uint32_t j = tid; j < n_eq; j += 1024u) {
+    for (uint32_t j = tid; j < n_eq; j += NT) {
         const uint32_t mine = e_idx[j];
         uint32_t before = 0u;
         for (uint32_t k = 0; k < n_eq; ++k) before += e_idx[k] < mine;
@@ -210,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_select_hot(const PairRec* __restrict__
     }
     __syncthreads();
     const uint32_t H = n_above + (n_eq < room ? n_eq : room);
-    for (uint32_t j = tid; j < H; j += 1024u) {
+    for (uint32_t j = tid; j < H; j += NT) {
         const uint32_t mine = h_idx[j];
         uint32_t before = 0u;
         for (uint32_t k = 0; k < H; ++k) before += h_idx[k] < mine;
@@ -264,7 +292,7 @@ void launch_select_hot(const PairRec* pairs, uint32_t* hist, uint32_t* hot_list,
 {
     if (npairs <= 0) return;
     if (keep > (int32_t)TOP6_MAX) keep = (int32_t)TOP6_MAX;
-    hipLaunchKernelGGL(k_select_hot, dim3(1), dim3(1024), 0, s, pairs, (const uint32_t*)hist, hot_list, keep);
+    hipLaunchKernelGGL(k_select_hot, dim3(1), dim3(HS_SEL_THREADS), 0, s, pairs, (const uint32_t*)hist, hot_list, keep);
     hipLaunchKernelGGL(k_write_perm, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, (const uint32_t*)hot_list, perm,
                        hist, npairs);
 }
