@@ -474,16 +474,23 @@ def main():
             el_route = timed(headline, 0, k_route)
             crc_route = crc(rt.read_dosage())
             exp_route = golden.get("route_flavour%d" % args.flavour) if args.seed_mode == 0 else None
+            # the same workload through the reference's own host loop with its device sync after every iteration
+            # (myapp.cpp:156-170): what an unmodified MyApp::Tick sees -- 12 launches between two syncs
+            el_tick = timed(step_loop_sync, 1, 1)
+            crc_tick = crc(rt.read_dosage())
             route_leg = {"workload": "lange_route.xml: %d lamps x %d iterations x %d photons = %d rays per computation (raytracer.h:30-32, "
                                      "myapp.cpp:156-170)" % (len(all_lamps), ROUTE_ITERATIONS, n_route, rays_route),
                          "mode": args.mode, "ms_per_computation": round(el_route / k_route * 1e3, 3),
                          "mray_s": round(rays_route * k_route / el_route / 1e6, 1), "computations_timed": k_route,
                          "cold_first_computation_ms": round(cold_ms, 3),
                          "cold_over_warm": round(cold_ms / (el_route / k_route * 1e3), 4),
+                         "unmodified_tick_loop": {"ms_per_computation": round(el_tick * 1e3, 3), "mray_s": round(rays_route / el_tick / 1e6, 1),
+                                                  "dose_crc32": crc_tick,
+                                                  "note": "mode loop_sync: ComputeDosageMap; Shade; sync per iteration, call by call (myapp.cpp:159-165)"},
                          "dose_crc32": crc_route, "dose_crc32_cold": crc_cold, "dose_crc32_expected": exp_route,
                          "note": "cold = the first computation over these 12 lamp positions (12 hot-record set-ups inside), bracketed "
                                  "by syncs, buffers allocated beforehand; expected CRC = the oracle's (tests/golden/make_bench_crc.py)"}
-            if crc_cold != crc_route or (exp_route is not None and crc_route != exp_route):
+            if crc_cold != crc_route or crc_tick != crc_route or (exp_route is not None and crc_route != exp_route):
                 raise SystemExit("bench: route workload dose CRC %s / %s differs from the oracle's %s" % (crc_cold, crc_route, exp_route))
             configure(headline_lamps, args.photons, args.waves)
         # timing pass for the roofline: the headline step with HIP events around the extend launches on their

@@ -183,9 +183,6 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.perm = gperm[g];
             p.recs_prepared = 1;
             p.refill_min = variant_refill_min(c->variant);
-            p.leaf_k = variant_leaf_k(c->variant);
-            p.leaf_p = variant_leaf_p(c->variant);
-            p.touch_pushed = variant_touch_pushed(c->variant, (size_t)c->npairs + (size_t)c->T);
             p.plane_batches = (uint32_t)(n_pad / 64);
             p.plane_n = (uint32_t)n;
             p.plane_stride = (uint32_t)plane_ints;

@@ -297,13 +297,10 @@ inline void split_bits(int bits, int& bphi, int& by, int& bo)
 // with refill at 16 idle lanes; 500-599 = the same with IEEE divisions everywhere; 600-899 = like 400-499
 // with the refill threshold 8 / 24 / 4 idle lanes.  (The v1-v5 kernels of round 1 are gone: see git history
 // and DESIGN.md section 4 for what they measured.)
-// 1000-1999 = the default kernel with another leaf-visit rule: 1000 + 100 * leaf_p + leaf_k (uvrt_extend6.hip
-// leaf_trip_rule: a lane at a leaf waits at most leaf_p trips, or until leaf_k lanes stand at one)
-// 900 / 901 = the default kernel with the touch of pushed records forced off / on (default: by the size of the scene)
 #ifdef UVRT_DEV_VARIANTS
-inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900) || v == 900 || v == 901 || (v >= 1100 && v < 2000 && v % 100 != 0); }
+inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900); }
 #else      // the product library holds the default kernel only: code 1 (leaf period 2, LDS cache) with any grid / refill knob
-inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900 && v % 10 == 1) || v == 900 || v == 901 || (v >= 1100 && v < 2000 && v % 100 != 0); }
+inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900 && v % 10 == 1); }
 #endif
 
 inline int auto_sort_bits(int64_t n)
@@ -325,14 +322,6 @@ inline int variant_per_cu(int v, int dflt)
     const int gcode = (v / 10) % 10;
     return !variant_is_knob(v) ? dflt : per_cu[gcode < 6 ? gcode : 0];
 }
-// records (64 B each) beyond which a pushed child's record is touched at the push: the XCD's 4 MiB L2 no longer holds
-// the tree (measured: profiles/r03_experiments.txt)
-constexpr size_t TOUCH_PUSHED_MIN_RECORDS = ((size_t)16 << 20) / 64;
-inline int variant_touch_pushed(int v, size_t records) { return v == 900 ? 0 : v == 901 ? 1 : records >= TOUCH_PUSHED_MIN_RECORDS ? 1 : 0; }
-constexpr int LEAF_P_DEFAULT = 2, LEAF_K_DEFAULT = 65;     // 65: never by lane count alone
-inline int variant_leaf_p(int v) { return v >= 1100 && v < 2000 ? (v - 1000) / 100 : LEAF_P_DEFAULT; }
-inline int variant_leaf_k(int v) { return v >= 1100 && v < 2000 ? (v - 1000) % 100 : LEAF_K_DEFAULT; }
-
 // The record renumbering for a launch from `lamp` on launch lane `lane` (stream `s`): the caller's own
 // (uvrt_set_record_perm), the automatic hot-record one (uvrt_hotset.hip: three small kernels enqueued on `s` the
 // first time the lamp is seen), or none.  (uvrt_capi_launch.hip)

@@ -212,8 +212,6 @@ struct ExtendParams {
     int32_t npairs;
     void* recs;              // extend v6: [npairs] per-launch pair records + [T] leaf records, 64 B each
     int32_t refill_min;      // extend v6: idle lanes that trigger a refill (16)
-    int32_t leaf_k, leaf_p;  // extend v6: lanes at a leaf that trigger a leaf trip at once / trips a leaf lane waits at most
-    int32_t touch_pushed;    // extend v6: 1 = a pushed child's record is touched (L2 prefetch) at the push; for scenes beyond L2
     const uint32_t* perm;    // extend v6: record renumbering (nullptr = identity), see prepare_record6
     int32_t recs_prepared;   // extend v6: recs[0, npairs) already hold this launch's records (k_generate)
     uint32_t root_ref6;      // root reference in v6's record numbering (set by launch_extend6)

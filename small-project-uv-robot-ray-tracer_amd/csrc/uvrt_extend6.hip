@@ -274,17 +274,13 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
 //   m3) use v47, v51-v55 and v57-v63 for the triangle test: the other lanes' copies of those registers are untouched
 //   m0 = inner lanes; m1 = lanes at a leaf, later "child 1 hit"; m2 = lanes with a cached record, later "child 0
 //   hit" (and the v_cmpx results of the triangle test); m3 = lanes visiting their leaf; m4 = scratch masks;
-//   %[code], %[t2] = scratch (lane counts, the leaf-trip decision) until %[code] carries the exit code
-// Leaf visits (leaf_trip_rule below has the same rule in C++): lanes that reach a leaf wait until the trip in which
-// at least leaf_k of the wave's lanes stand at one, or leaf_p trips have passed since the last leaf visit (%[km]
-// counts them down), or no lane is left at an inner node -- the ~55 instructions of the triangle test then serve
-// several lanes instead of one or two.
-// Touch of the pushed child (p.touch_pushed, scenes whose records do not fit in L2): a node that is pushed IS visited
-// later (the reference pops and visits without another test, extend.cl:77-79), so its record is fetched for certain --
-// a one-dword load of it, past L1 (sc1), issued at the push brings the line into L2 while the nearer subtree is walked.
-// Its destination v55 is the one register of the record window nobody reads: the fourth dword of the refs quarter of a
-// pair record (zero), dead in the triangle test by then; vector-memory loads return in issue order, so the next trip's
-// record load lands after it, and the stream waits for it before it leaves.
+//   %[code] = scratch (lane count, leaf-trip flag) until it carries the exit code
+// Tried and measured in round 3 (profiles/r03_experiments.txt), both bit-exact, neither kept:
+//  * an adaptive leaf rule (leaf trip when >= K lanes stand at a leaf or P trips after the last leaf visit; git cc58a8b):
+//    no (P, K) beat the fixed alternation, and its seven extra scalar instructions per trip cost 0.8 %;
+//  * a one-dword load past L1 (sc1) of a pushed child's record at the push -- a pushed node IS visited later,
+//    extend.cl:77-79 -- into the one dead register of the record window, v55: -10.7 % on the room, -2.9 % on a
+//    6 M-triangle soup beyond every cache.
 // Arithmetic: slabs / boxes / hit tests are step7's (slabs6, box2_fast, the v_cmpx tail); the triangle test is
 // tri6<OCL> instruction for instruction (extend.cl:6-27), early returns as v_cmpx narrowing of exec.
 // A kernel with this stream must not spill: scratch use costs the launch pipelining 14 % (measured); the general
@@ -345,12 +341,9 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "s_or_b64 %[m4], vcc, %[spec]\n\t" \
         "s_cbranch_scc1 8f\n\t" \
         "v_cmp_gt_u32_e64 %[m2], %[tp], %[cur]\n\t" \
-        "s_bcnt1_i32_b64 %[code], %[m1]\n\t"           /* leaf trip: enough lanes stand at a leaf ... */ \
-        "s_cmp_ge_u32 %[code], %[kk]\n\t" \
-        "s_cselect_b32 %[code], 1, %[km]\n\t"          /* ... or the wait since the last leaf visit is over ... */ \
         "s_cmp_eq_u64 %[m0], 0\n\t" \
-        "s_cselect_b32 %[code], 1, %[code]\n\t"        /* ... or no lane stands at an inner node */ \
-        "s_cmp_le_u32 %[code], 1\n\t" \
+        "s_cselect_b32 %[code], -1, %[km]\n\t" \
+        "s_cmp_lg_u32 %[code], 0\n\t" \
         "s_cselect_b64 %[m3], %[m1], 0\n\t" \
         "s_cmp_lg_u64 %[m3], 0\n\t" \
         "s_cbranch_scc0 3f\n\t" \
@@ -361,10 +354,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "s_cmp_lg_u64 %[m4], 0\n\t" \
         "s_cbranch_scc1 8f\n\t" \
         "3:\n\t" \
-        "s_sub_u32 %[t2], %[km], 1\n\t"                /* the wait counts down to 1 ... */ \
-        "s_max_u32 %[t2], %[t2], 1\n\t" \
-        "s_cmp_lg_u64 %[m3], 0\n\t" \
-        "s_cselect_b32 %[km], %[pp], %[t2]\n\t"        /* ... and restarts at the period when leaves are visited */ \
+        "s_not_b32 %[km], %[km]\n\t" \
         "v_lshl_add_u32 v57, %[sp], 10, %[sb]\n\t" \
         "v_mul_u32_u24 v52, 0x40, %[cur]\n\t" \
         "v_add_u32 v52, %[tb], v52\n\t" \
@@ -443,11 +433,6 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "v_cndmask_b32 v63, v53, v52, %[m4]\n\t" \
         "ds_write_b32 v57, v63 offset:1024\n\t" \
         "v_add_u32 %[sp], 1, %[sp]\n\t" \
-        "s_bitcmp1_b32 %[pf], 0\n\t"                   /* scenes beyond L2: touch the pushed child's record now (below) */ \
-        "s_cbranch_scc0 6f\n\t" \
-        "v_lshlrev_b32 v59, 6, v63\n\t" \
-        "global_load_dword v55, v59, %[rb] sc1\n\t" \
-        "6:\n\t" \
         "s_or_b64 exec, %[m2], %[m1]\n\t" \
         "v_cndmask_b32 %[cur], v52, v53, %[m4]\n\t" \
         "s_andn2_b64 %[m4], %[m0], exec\n\t" \
@@ -467,15 +452,14 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "s_branch 9f\n\t" \
         "8:\n\t" \
         "s_mov_b32 %[code], 2\n\t" \
-        "9:\n\t" \
-        "s_waitcnt vmcnt(0)"                             /* a touch of the last trip may still be on its way to v55 */
+        "9:"
 
 #define R7_OPERANDS \
-        : [cur] "+v"(L.cur), [sp] "+v"(L.sp), [dist] "+v"(dist), [tri] "+v"(L.triID), [km] "+s"(km), [code] "=&s"(code), [t2] "=&s"(t2), \
+        : [cur] "+v"(L.cur), [sp] "+v"(L.sp), [dist] "+v"(dist), [tri] "+v"(L.triID), [km] "+s"(km), [code] "=&s"(code), \
           [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4) \
         : [px] "v"(L.px), [py] "v"(L.py), [pz] "v"(L.pz), [po] "v"(L.po), [dx] "v"(L.px.x), [dy] "v"(L.py.x), [dz] "v"(L.pz.x), \
           [oy] "v"(oy), [sb] "v"(stack_base), [tb] "s"(__builtin_amdgcn_readfirstlane(top_base)), [full] "s"(full), [rb] "s"(p.recs), [spec] "s"(special_mask), \
-          [tp] "s"(top_pairs), [amin] "s"(active_min), [ox] "s"(p.ox), [oz] "s"(p.oz), [kk] "s"(p.leaf_k), [pp] "s"(p.leaf_p), [pf] "s"(p.touch_pushed) \
+          [tp] "s"(top_pairs), [amin] "s"(active_min), [ox] "s"(p.ox), [oz] "s"(p.oz) \
         : "memory", "scc", "vcc", R7_CLOBBERS
 
 template <bool OCL, int LEAFP>
@@ -483,8 +467,9 @@ __device__ __forceinline__ int run7(Lane6& L, const ExtendParams& p, uint32_t st
                                     uint32_t top_pairs, unsigned long long special_mask, int& km,
                                     unsigned long long full, int active_min)
 {
+    static_assert(LEAFP == 2, "run7 visits leaves in every second trip");
     static_assert(TOP6_STRIDE == 0x40, "run7 multiplies by the literal stride of the LDS cache");
-    int code, t2;
+    int code;
     unsigned long long m0, m1, m2, m3, m4;   // scalar temporaries of the stream: lane masks
     // {d, 1/d} per axis, {origin y, dist}: the scalar halves are separate operands (an asm operand has no
     // sub-register syntax), tied to the same registers as the pairs by construction of Lane6
@@ -509,16 +494,6 @@ __device__ __forceinline__ bool outside_proof_conditions(float4 rec)
     const uint32_t uo = __float_as_uint(rec.w) & 0x7FFFFFFFu;                   // |origin y|
     const uint32_t ylo = 0x0D800000u /* 2^-100 = 7.888609e-31f */, yhi = 0x4E6E6B28u /* 1e9f */;
     return worst > one - lo || (uo != 0u && uo - ylo > yhi - ylo);
-}
-
-// Whether the lanes that stand at a leaf (m_lf) visit it in this trip -- run7's rule in C++, for the trips that leave
-// the stream: enough of them (leaf_k), or the wait since the last leaf visit is over (kwait counts down from leaf_p
-// to 1), or no lane is left at an inner node (m_in).
-__device__ __forceinline__ bool leaf_trip_rule(unsigned long long m_in, unsigned long long m_lf, int& kwait, int leaf_k, int leaf_p)
-{
-    const bool leaf_trip = m_in == 0 || __popcll(m_lf) >= leaf_k || kwait <= 1;
-    kwait = (leaf_trip && m_lf != 0) ? leaf_p : (kwait > 2 ? kwait - 1 : 1);
-    return leaf_trip;
 }
 
 template <int LEAFP, bool RECORD, bool TOP, bool OCL>
@@ -559,7 +534,8 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     uint32_t cursor = 0;
     const uint32_t chunk_end = p.chunk;
     const uint32_t n32 = (uint32_t)p.n;
-    int kwait_c = 1;                        // the C++ trips' wait counter of leaf_trip_rule
+    uint32_t trip = 0;
+    unsigned long long km = ~0ull;          // all ones in a trip that visits leaves (every LEAFP-th)
     unsigned long long full;                // exec of the loop: all 64 lanes (the launch uses full workgroups)
     asm volatile("s_mov_b64 %0, exec" : "=s"(full));
     const uint32_t top_base = (uint32_t)(uintptr_t)s_top;
@@ -580,17 +556,17 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     constexpr bool asm_trips = TOP && LEAFP == 2;
 #endif
     if constexpr (asm_trips) {
-        int kwait = 1;                          // trips until waiting leaf lanes are visited at the latest (1 = this trip)
+        int kflag = -1;                         // -1 in a trip that visits leaves (every second one)
         for (;;) {
             // common trips back to back (run7), until lanes want new rays (1) or a trip needs the general step (2)
             // (scalars that pass through the asm statement are re-declared uniform: hipcc otherwise treats them, and
             // every loop-carried scalar whose update depends on them, as divergent and keeps them in vector registers)
             // (two call sites: a select between the two thresholds would drag `cursor` into a vector register)
             int why;
-            if (cursor < chunk_end) why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kwait, full, 64 - refill_c);
-            else why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kwait, full, 0);
+            if (cursor < chunk_end) why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 64 - refill_c);
+            else why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 0);
             why = __builtin_amdgcn_readfirstlane(why);
-            kwait = __builtin_amdgcn_readfirstlane(kwait);
+            kflag = __builtin_amdgcn_readfirstlane(kflag);
             if (why == 1) {
                 const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(L.cur == REF_DONE);
                 const int nidle = __popcll(idle_mask);
@@ -645,7 +621,8 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             }
             const unsigned long long m_in = __builtin_amdgcn_ballot_w64((int32_t)L.cur >= 0);
             const unsigned long long m_lf = __builtin_amdgcn_ballot_w64((int32_t)L.cur < -1);
-            const bool leaf_trip = leaf_trip_rule(m_in, m_lf, kwait, p.leaf_k, p.leaf_p);
+            const bool leaf_trip = m_in == 0 || kflag != 0;
+            kflag = ~kflag;
             // (two specialisations of the general step -- hipcc's register allocation for the one with both
             // arithmetic forms does not fit beside the registers run7 reserves)
             if ((special_mask & (m_in | m_lf)) != 0) step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, true, m_in | m_lf);
@@ -720,9 +697,13 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
         const unsigned long long m_lf = __builtin_amdgcn_ballot_w64((int32_t)L.cur < -1);
         const unsigned long long m_top = TOP ? __builtin_amdgcn_ballot_w64(L.cur < top_pairs) : 0ull;
         const unsigned long long m_deep = __builtin_amdgcn_ballot_w64(L.sp >= PS6);
-        // leaf_trip_rule: leaves are visited at most every LEAFP-th trip unless leaf_k lanes wait or no lane is at an inner node
-        unsigned long long kme = ~0ull;
-        if (LEAFP > 1) kme = leaf_trip_rule(m_in, m_lf, kwait_c, p.leaf_k, LEAFP == 2 ? p.leaf_p : LEAFP) ? ~0ull : 0ull;
+        // leaves are visited in every LEAFP-th trip, and in any trip that has no lane at an inner node
+        unsigned long long kme = km;
+        if (LEAFP > 1) {
+            kme = m_in == 0 ? ~0ull : km;
+            if (LEAFP == 2) km = ~km;
+            else { ++trip; if (trip == (uint32_t)LEAFP) trip = 0; km = trip == 0 ? ~0ull : 0ull; }
+        }
         // the common case in its lane-mask form; a trip with a lane that needs IEEE divisions (the bit of a
         // finished lane stays set until the next refill: the exact form is right for every lane) or whose stack
         // has left LDS takes the general step
@@ -827,8 +808,6 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
     }
     p.plane_inv = 1.0f / (float)p.plane_batches;
     p.refill_min = p.refill_min < 1 ? 1 : (p.refill_min > 64 ? 64 : p.refill_min);
-    p.leaf_k = p.leaf_k < 1 ? 65 : p.leaf_k;          // 0 = unset: never by lane count alone
-    p.leaf_p = p.leaf_p < 1 ? 2 : p.leaf_p;           // 0 = unset: every second trip
     const unsigned need = (unsigned)((p.n + 255) / 256);
     if (need < grid) grid = need;
     const uint64_t waves = (uint64_t)grid * 4;

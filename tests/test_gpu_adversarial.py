@@ -13,7 +13,7 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def run_both(pkg, orc, tris, nodes, idx, rays, variants=(0, 401, 501, 801, 901, 405, 500)):
+def run_both(pkg, orc, tris, nodes, idx, rays, variants=(0, 401, 501, 801, 405, 500)):
     o_rays = rays.copy()
     o_rays["dist"] = np.float32(1e30)
     o_rays["triID"] = 0

@@ -361,3 +361,51 @@ def test_group_collective_rejects_what_it_cannot_reduce(pkg, orc, oscene, oroute
     finally:
         a.close()
         b.close()
+
+
+def test_cu_reservation_for_the_collective_keeps_the_bits(pkg, orc, oscene, oroute):
+    """While a communicator is set the launch lanes' streams carry a CU mask (one CU per XCD left to the context's stream
+    for fold / all-reduce / replay, uvrt_capi_comm.hip set_lane_cu_mask) and the persistent grid shrinks to the CUs that are
+    left: same counts and dose as without; the lanes get their plain streams back when the communicator goes."""
+    lamps = [lamp_pos(orc, oscene, oroute, k) for k in (3, 4)]
+    n = 400000
+    a = pkg.capi.Ctx(0)
+    b = pkg.capi.Ctx(0)
+    try:
+        for c in (a, b):
+            c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+            c.reset(True)
+        ops = make_ops(pkg, [60.0, 20.0], {1: 0}, n)
+        a.trace_batch(lamps, 1.0, 0, n)
+        want = [a.read_batch_counts(k) for k in range(2)]
+        a.replay_batch(ops)
+        b.comm_init_rank(pkg.capi.comm_unique_id(), 0, 1)             # lanes now masked
+        for rnd in range(2):                                          # twice: both buffer sets, both lanes
+            b.reset(True)
+            b.seed = 0
+            b.trace_batch(lamps, 1.0, 0, n)
+            b.reduce_batch()
+            for k in range(2):
+                assert np.array_equal(b.read_batch_counts(k), want[k]), (rnd, k)
+            b.replay_batch(ops)
+            assert np.array_equal(bits(a.read_dosage()), bits(b.read_dosage()))
+        # the per-launch path on the masked lanes
+        rays, _ = orc.generate(0, n, lamps[0], 1.0, 0)
+        temp = np.zeros(oscene.T, dtype=np.int32)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        for _ in range(3):                                            # lanes 0, 1, 0 ...
+            b.resize_rays(n)
+            b.reset(False)
+            b.seed = 0
+            b.generate(lamps[0], 1.0, 0, n)
+            b.extend(n)
+            assert np.array_equal(b.read_counts(), temp)
+        b.comm_destroy()                                              # plain streams again
+        b.reset(True)
+        b.seed = 0
+        b.trace_batch(lamps, 1.0, 0, n)
+        b.replay_batch(ops)
+        assert np.array_equal(bits(a.read_dosage()), bits(b.read_dosage())) and a.read_dosage().any()
+    finally:
+        a.close()
+        b.close()

@@ -82,16 +82,16 @@ def test_extend_hits_and_counts_bit_exact(ctx, orc, oscene, oroute, sort_bits):
     ctx.set_record_hits(False)
 
 
-@pytest.mark.parametrize("variant", [0, 400, 401, 402, 403, 404, 405, 406, 407, 411, 421, 431, 441, 500, 501, 505, 601, 702, 801, 901, 1208, 1316, 1101])
+@pytest.mark.parametrize("variant", [0, 400, 401, 402, 403, 404, 405, 406, 407, 411, 421, 431, 441, 500, 501, 505, 601, 702, 801])
 def test_every_extend_variant_is_bit_exact(pkg, ctx, ctx_dev, orc, oscene, oroute, variant):
     """All kernel knob settings (leaf period, LDS top cache on / off, 2-16 workgroups per CU, refill
-    thresholds, IEEE divisions everywhere, the touch of pushed records (901), leaf-visit rules (11xx-19xx)) give the
+    thresholds, IEEE divisions everywhere) give the
     same bits: layout and scheduling never change results.
     Knobs that select another instantiation than the product's run on the developer build of the library."""
     _variant_case(ctx_dev if pkg.capi.needs_dev(variant) else ctx, orc, oscene, oroute, variant, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 400, 401, 403, 404, 405, 421, 500, 501, 505, 601, 801, 901, 1212])
+@pytest.mark.parametrize("variant", [0, 400, 401, 403, 404, 405, 421, 500, 501, 505, 601, 801])
 def test_every_v6_variant_is_bit_exact_in_the_ocl_flavour(pkg, ctx, ctx_dev, orc, oscene, oroute, variant):
     """flavour 1 (fused cross/dot of ROCm's OpenCL library, uvrt_set_flavour) on the default kernel and
     its variants (leaf period, LDS top cache, grid, refill threshold, IEEE divisions) against the

@@ -123,7 +123,7 @@ def test_deep_stack_uses_overflow_and_matches_oracle(pkg, orc, depth):
     temp = np.zeros(tris.shape[0], dtype=np.int32)
     st = orc.extend(temp, tris, rays, nodes, idx)
     assert st["max_stack"] == depth and st["hits"] > 0
-    for variant in (0, 411, 501, 901, 404, 500):
+    for variant in (0, 411, 501, 404, 500):
         c = pkg.capi.Ctx(0, dev=pkg.capi.needs_dev(variant))
         c.set_scene(tris, nodes, idx)
         c.resize_rays(n)
