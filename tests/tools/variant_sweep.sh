@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer probe: bench.py (loop mode, no CPU leg) for a list of extend kernel knob settings (uvrt_set_variant)
 mkdir -p gpurun_out/sweep
-for v in ${VARIANTS:-0 600 601 602 603 801 802 701 401 402 621 641}; do
+for v in ${VARIANTS:-0 601 801 701 401 411 421 451 621 641}; do
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --variant $v 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline'] or {}
