@@ -50,6 +50,7 @@ int uvrt_create(int device_id, uvrt_ctx** out)
                     device_id, prop.gcnArchName);
     uvrt_ctx* c = new uvrt_ctx();
     c->device = device_id;
+    c->hot.reserve(uvrt_ctx::HOT_MAX);         // entries are referred to by pointer while their set-up is pending
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (c->num_cus > 256) c->num_cus = 256;   // the overflow-stack buffer is sized for 256 CUs x 16 workgroups
     if (const char* e = getenv("UVRT_REPLICAS")) {   // developer knob: deposit replicas of tempPhotonMap

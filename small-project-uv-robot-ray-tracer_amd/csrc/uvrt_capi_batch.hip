@@ -69,17 +69,32 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                             S.folded.bytes < (size_t)count * (size_t)c->T * 4 || (int)c->b_recs.size() < ngroups || !S.free_ev;
     bool recs_stale = false;
     const uint32_t* gperm[MAX_BATCH] = {};
+    uvrt_ctx::HotEntry* fresh[MAX_BATCH];               // lamps the context has not seen: their set-ups go in ONE launch
+    uint32_t fresh_prev[MAX_BATCH], fresh_next[MAX_BATCH];
+    int nfresh = 0;
     for (int g = 0; g < ngroups; ++g) {
         gperm[g] = c->have_perm ? c->perm.as<uint32_t>() : nullptr;
+        bool is_fresh = false;
         if (!gperm[g] && (int64_t)gsize[g] * n >= 16384) {
             const int ph = gfirst[g];      // the group's first launch lends its lamp and seeds to the statistics
             const float gl[3] = {gp.lx[ph], gp.ly[ph], gp.lz[ph]};
-            if (int rcp = launch_perm(c, gl, light_length, gp.seed_prev[ph], gp.seed_next[ph], c->stream, 0, &gperm[g])) return rcp;
+            uvrt_ctx::HotEntry* e = nullptr;
+            if (int rcp = hot_lookup(c, gl, c->stream, &gperm[g], &e)) return rcp;
+            if (e) {
+                gperm[g] = e->perm;
+                fresh[nfresh] = e; fresh_prev[nfresh] = gp.seed_prev[ph]; fresh_next[nfresh] = gp.seed_next[ph];
+                ++nfresh;
+                is_fresh = true;
+            }
         }
         if (g >= (int)c->b_recs_key.size() || c->b_recs_key[g].perm != gperm[g] || memcmp(&c->b_recs_key[g].ox, &gx[g], 4) != 0 ||
-            memcmp(&c->b_recs_key[g].oz, &gz[g], 4) != 0)
+            memcmp(&c->b_recs_key[g].oz, &gz[g], 4) != 0 || is_fresh) {
             recs_stale = true;
+            if (g < (int)c->b_recs_key.size()) c->b_recs_key[g].valid = false;
+        }
     }
+    if (nfresh > 0)
+        if (int rcb = hot_build(c, fresh, fresh_prev, fresh_next, nfresh, light_length, c->stream, 0)) return rcb;
     if (need_alloc || recs_stale) {
         if (int rcj = join_all(c)) return rcj;
     }

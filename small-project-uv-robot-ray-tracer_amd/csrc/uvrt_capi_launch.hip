@@ -19,16 +19,18 @@ int hot_reset(uvrt_ctx* c, bool slab)
     c->hot_slabs.emplace_back();
     if (int rc = c->hot_slabs.back().ensure((size_t)uvrt_ctx::HOT_SLAB * (size_t)c->npairs * 4, false, c->stream)) return rc;
     for (int l = 0; l < c->nlanes || l < 3; ++l) {
-        if (int rc = c->hot_hist[l].ensure((size_t)c->npairs * 4, true, c->stream)) return rc;
-        if (int rc = c->hot_list[l].ensure(((size_t)TOP6_MAX + 1) * 4, false, c->stream)) return rc;
+        // lane 0 (uvrt_trace_batch) sets up all new lamps of a batch in one launch: room for HS_GROUPS of them where that is small
+        const size_t groups = (l == 0 && (size_t)c->npairs * 4 * HS_GROUPS <= ((size_t)64 << 20)) ? (size_t)HS_GROUPS : 1;
+        if (int rc = c->hot_hist[l].ensure(groups * (size_t)c->npairs * 4, true, c->stream)) return rc;
+        if (int rc = c->hot_list[l].ensure(groups * ((size_t)TOP6_MAX + 1) * 4, false, c->stream)) return rc;
     }
     return UVRT_OK;
 }
 
-int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t seed_prev, uint32_t seed_next,
-                hipStream_t s, int lane, const uint32_t** out)
+int hot_lookup(uvrt_ctx* c, const float lamp[3], hipStream_t s, const uint32_t** out, uvrt_ctx::HotEntry** fresh)
 {
     *out = nullptr;
+    *fresh = nullptr;
     if (c->have_perm) { *out = c->perm.as<uint32_t>(); return UVRT_OK; }
     if (c->hot_mode == 0 || c->npairs <= (int32_t)128 || c->root_ref >= REF_LEAF_BIT) return UVRT_OK;
     ++c->hot_clock;
@@ -53,7 +55,7 @@ int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t s
         memset(&ne, 0, sizeof ne);
         ne.perm = c->hot_slabs[idx / uvrt_ctx::HOT_SLAB].as<uint32_t>() + (idx % uvrt_ctx::HOT_SLAB) * (size_t)c->npairs;
         HIP_TRY(hipEventCreateWithFlags(&ne.ready, hipEventDisableTiming));
-        c->hot.push_back(ne);
+        c->hot.push_back(ne);                 // (the vector's capacity is HOT_MAX from the start: entries never move)
         e = &c->hot.back();
     } else {          // recycle the least recently used entry: nothing in flight may still read its renumbering
         if (int rc = join_all(c)) return rc;
@@ -61,26 +63,58 @@ int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t s
         e = &c->hot[0];
         for (auto& h : c->hot) if (h.stamp < e->stamp) e = &h;
     }
-    // scratch of the set-up kernels, per launch lane: visit counters (zero between uses) and the hot list
-    if (int rc = c->hot_hist[lane].ensure((size_t)c->npairs * 4, true, s)) return rc;
-    if (int rc = c->hot_list[lane].ensure(((size_t)TOP6_MAX + 1) * 4, false, s)) return rc;
     memcpy(e->lamp, lamp, 12);
     e->stamp = c->hot_clock;
-    SceneDev sc;
-    sc.pairs = c->pairs.as<PairRec>();
-    sc.ltris = c->ltris.as<LeafTri>();
-    sc.leaf_count = c->leaf_count.as<uint32_t>();
-    sc.root_ref = c->root_ref;
-    sc.tri_count = c->T;
-    // the statistics always sample global ids [0, HOT_SAMPLE) of the lamp (the kernel makes its own rays), whichever
-    // range of the launch this context traces
-    launch_visit_stats(sc, c->hot_hist[lane].as<uint32_t>(), lamp, light_length, seed_prev, seed_next, c->seed_mode,
-                       c->hot_sample, s);
-    launch_select_hot(c->pairs.as<PairRec>(), c->hot_hist[lane].as<uint32_t>(), c->hot_list[lane].as<uint32_t>(), e->perm,
-                      c->npairs, (int32_t)TOP6_MAX, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ready, s));
-    *out = e->perm;
+    *fresh = e;
+    return UVRT_OK;
+}
+
+int hot_build(uvrt_ctx* c, uvrt_ctx::HotEntry* const* entries, const uint32_t* seed_prev, const uint32_t* seed_next, int count,
+              float light_length, hipStream_t s, int lane)
+{
+    for (int k0 = 0; k0 < count; k0 += HS_GROUPS) {
+        const int kc = std::min(HS_GROUPS, count - k0);
+        // scratch of the set-up kernels, per launch lane: visit counters (zero between uses) and the hot lists
+        if (int rc = c->hot_hist[lane].ensure((size_t)kc * (size_t)c->npairs * 4, true, s)) return rc;
+        if (int rc = c->hot_list[lane].ensure((size_t)kc * ((size_t)TOP6_MAX + 1) * 4, false, s)) return rc;
+        HotSetupParams p;
+        memset(&p, 0, sizeof p);
+        p.pairs = c->pairs.as<PairRec>();
+        p.ltris = c->ltris.as<LeafTri>();
+        p.leaf_count = c->leaf_count.as<uint32_t>();
+        p.root_ref = c->root_ref;
+        p.light_length = light_length;
+        p.seed_mode = c->seed_mode;
+        // the statistics always sample global ids [0, hot_sample) of the lamp (the kernel makes its own rays), whichever
+        // range of the launch this context traces
+        p.n = c->hot_sample;
+        p.npairs = c->npairs;
+        p.keep = (int32_t)TOP6_MAX;
+        p.count = kc;
+        p.hist = c->hot_hist[lane].as<uint32_t>();
+        p.hot_list = c->hot_list[lane].as<uint32_t>();
+        for (int k = 0; k < kc; ++k) {
+            const uvrt_ctx::HotEntry* e = entries[k0 + k];
+            p.perm[k] = e->perm;
+            p.lx[k] = e->lamp[0]; p.ly[k] = e->lamp[1]; p.lz[k] = e->lamp[2];
+            p.seed_prev[k] = seed_prev[k0 + k];
+            p.seed_next[k] = seed_next[k0 + k];
+        }
+        launch_hot_setup(p, s);
+        HIP_TRY(hipGetLastError());
+        for (int k = 0; k < kc; ++k) HIP_TRY(hipEventRecord(entries[k0 + k]->ready, s));
+    }
+    return UVRT_OK;
+}
+
+int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t seed_prev, uint32_t seed_next,
+                hipStream_t s, int lane, const uint32_t** out)
+{
+    uvrt_ctx::HotEntry* fresh = nullptr;
+    if (int rc = hot_lookup(c, lamp, s, out, &fresh)) return rc;
+    if (!fresh) return UVRT_OK;
+    if (int rc = hot_build(c, &fresh, &seed_prev, &seed_next, 1, light_length, s, lane)) return rc;
+    *out = fresh->perm;
     return UVRT_OK;
 }
 

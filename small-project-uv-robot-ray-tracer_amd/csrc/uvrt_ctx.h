@@ -327,6 +327,11 @@ inline int variant_per_cu(int v, int dflt)
 // first time the lamp is seen), or none.  (uvrt_capi_launch.hip)
 int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t seed_prev, uint32_t seed_next,
                 hipStream_t s, int lane, const uint32_t** out);
+// the two halves of launch_perm: the cached renumbering of `lamp` (*out), or a reserved entry (*fresh, its `perm` pointer
+// already final) whose set-up hot_build enqueues on `s` -- for several new lamps at once in ONE launch of each kernel
+int hot_lookup(uvrt_ctx* c, const float lamp[3], hipStream_t s, const uint32_t** out, uvrt_ctx::HotEntry** fresh);
+int hot_build(uvrt_ctx* c, uvrt_ctx::HotEntry* const* entries, const uint32_t* seed_prev, const uint32_t* seed_next, int count,
+              float light_length, hipStream_t s, int lane);
 // drops every cached renumbering (a new scene); with `slab`, the first slab of the new scene is allocated at once
 int hot_reset(uvrt_ctx* c, bool slab);
 // (re)creates the side lanes' streams with `reserve` CUs masked out, one per XCD and mask word of 8 (0: plain streams)

@@ -247,12 +247,24 @@ bool launch_extend6(const ExtendParams& p, int code, int grid_per_cu, hipStream_
 // the opt-in 4-wide traversal (uvrt_extend4.hip)
 bool launch_extend4(const ExtendParams& p, int grid_per_cu, hipStream_t s);
 void launch_prepare_launch4(const QuadRec* quads, void* recs4, float ox, float oz, int32_t nquads, hipStream_t s);
-// hot-record statistics (uvrt_hotset.hip)
-void launch_visit_stats(const SceneDev& scene, uint32_t* hist, const float lamp[3], float light_length, uint32_t seed_prev,
-                        uint32_t seed_next, int32_t seed_mode, int32_t n, hipStream_t s);
-// hot_list: [TOP6_MAX + 1] scratch (count + ascending indices); writes perm[0, npairs) and zeroes hist again
-void launch_select_hot(const PairRec* pairs, uint32_t* hist, uint32_t* hot_list, uint32_t* perm, int32_t npairs, int32_t keep,
-                       hipStream_t s);
+// hot-record set-up (uvrt_hotset.hip): visit statistics -> selection -> renumbering for up to HS_GROUPS lamps at once
+constexpr int HS_GROUPS = 16;
+struct HotSetupParams {
+    const PairRec* pairs;
+    const LeafTri* ltris;
+    const uint32_t* leaf_count;
+    uint32_t root_ref;
+    float light_length;
+    int32_t seed_mode;
+    int32_t n;                         // photons of the launch whose visits are counted (global ids [0, n))
+    int32_t npairs, keep, count;       // records, hot records wanted, lamps
+    uint32_t* hist;                    // [count][npairs] visit counters: zero before, zero again after
+    uint32_t* hot_list;                // [count][TOP6_MAX + 1] scratch: number of hot records + their indices, ascending
+    uint32_t* perm[HS_GROUPS];         // out: the renumbering of lamp k, [npairs]
+    float lx[HS_GROUPS], ly[HS_GROUPS], lz[HS_GROUPS];
+    uint32_t seed_prev[HS_GROUPS], seed_next[HS_GROUPS];
+};
+void launch_hot_setup(const HotSetupParams& p, hipStream_t s);
 void launch_prepare_leaves6(const LeafTri* ltris, void* recs, int32_t npairs, int32_t T, hipStream_t s);
 constexpr uint64_t OVF_MAX_ENTRIES = (uint64_t)256 * 16 * 256 * 24;   // largest grid x deepest overflow
 void launch_accumulate(double* photon_map, double* max_map, int32_t* counts, int32_t replicas,

@@ -3,7 +3,8 @@
 // The traversal kernel (uvrt_extend6.hip) serves the first records of its numbering from LDS.  Which
 // records are hot depends on the lamp: the 127 most visited ones take 62-70 % of all inner-node visits on
 // the test room (the cache holds 175), the first 127 in breadth-first order 31-40 % (profiles/r02_record_layout_experiment.txt).
-// For every new lamp position the context therefore enqueues three small kernels on the launch's stream:
+// For every new lamp position the context therefore enqueues three small kernels on the launch's stream (the new lamps of
+// one uvrt_trace_batch call share ONE launch of each: blockIdx.y = the lamp):
 //   1. k_visit_stats -- traces a sample of the launch's own photons (global ids [0, S)): a plain
 //      one-ray-per-lane closest-hit traversal in fast arithmetic that only COUNTS inner-node visits.  The
 //      counters of the top of the tree (breadth-first indices < HS_LDS_BINS, where every ray of a workgroup
@@ -33,17 +34,8 @@ constexpr int HS_CAND = 4096;         // candidate records of k_select_hot
 constexpr int HS_EQ = 1024;           // candidates AT the threshold that take part in the tie-break by index
 constexpr int HS_MAX_STEPS = 64;      // traversal steps of a sample ray that are counted (99 % of the test room's rays take fewer)
 
-struct StatParams {
-    const PairRec* pairs;
-    const LeafTri* ltris;
-    const uint32_t* leaf_count;
-    uint32_t* hist;          // [npairs] visit counts, zero before the launch
-    uint32_t root_ref;
-    float lx, ly, lz, light_length;
-    uint32_t seed_prev, seed_next;
-    int32_t seed_mode;
-    int32_t n;
-};
+// Several lamps' set-ups in one launch of each kernel (uvrt_device.h HotSetupParams): blockIdx.y = the lamp.
+typedef HotSetupParams StatParams;
 
 __device__ __forceinline__ bool box_approx(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float ox,
                                            float oy, float oz, float ix, float iy, float iz, float dist, float& tmin)
@@ -65,11 +57,14 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     for (int i = tid; i < HS_LDS_BINS; i += 256) s_hist[i] = 0u;
     __syncthreads();
     const int gid = blockIdx.x * 256 + tid;
+    const int grp = blockIdx.y;                                       // the lamp of this workgroup
+    uint32_t* const hist = p.hist + (size_t)grp * (size_t)p.npairs;
     uint32_t cur = (gid < p.n && p.root_ref < REF_LEAF_BIT) ? p.root_ref : REF_DONE;
     float r0;
     double sx, sy;
-    const float4 ray = generate_ray(p.lx, p.ly, p.lz, p.light_length, gid, p.seed_prev, p.seed_next, p.seed_mode, r0, sx, sy);
-    const float ox = p.lx, oy = ray.w, oz = p.lz;
+    const float4 ray = generate_ray(p.lx[grp], p.ly[grp], p.lz[grp], p.light_length, gid, p.seed_prev[grp], p.seed_next[grp], p.seed_mode,
+                                    r0, sx, sy);
+    const float ox = p.lx[grp], oy = ray.w, oz = p.lz[grp];
     const float dx = ray.x, dy = ray.y, dz = ray.z;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     float dist = 1e30f;
@@ -80,7 +75,7 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     // would put its round trip to the memory side (600-3000 cycles) in front of the next trip's record fetch.
     auto flush_queue = [&]() {
         for (int e = 0; e < HS_QUEUE; ++e)
-            if (e < qn) atomicAdd(&p.hist[s_queue[e][tid]], 1u);
+            if (e < qn) atomicAdd(&hist[s_queue[e][tid]], 1u);
         qn = 0;
     };
     // One step per trip, ONE memory round trip per step: the 64 bytes at the lane's record -- a node-pair record or a
@@ -138,15 +133,17 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     __syncthreads();
     for (int i = tid; i < HS_LDS_BINS; i += 256) {
         const uint32_t v = s_hist[i];
-        if (v) atomicAdd(&p.hist[i], v);          // only bins below npairs are ever counted
+        if (v) atomicAdd(&hist[i], v);            // only bins below npairs are ever counted
     }
 }
 
 // hot[0] = H (number of hot records, <= keep), hot[1 .. H] = their indices in ascending order.  One workgroup.
 constexpr int HS_SEL_THREADS = 256;
-__global__ __launch_bounds__(HS_SEL_THREADS) void k_select_hot(const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hist,
-                                                             uint32_t* __restrict__ hot, int32_t keep)
+__global__ __launch_bounds__(HS_SEL_THREADS) void k_select_hot(const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hist_all,
+                                                             uint32_t* __restrict__ hot_all, int32_t npairs, int32_t keep)
 {
+    const uint32_t* __restrict__ hist = hist_all + (size_t)blockIdx.x * (size_t)npairs;      // one workgroup per lamp
+    uint32_t* __restrict__ hot = hot_all + (size_t)blockIdx.x * (TOP6_MAX + 1);
     __shared__ uint32_t c_idx[HS_CAND], c_cnt[HS_CAND];
     __shared__ uint32_t e_idx[HS_EQ];                 // candidates at the threshold
     __shared__ uint32_t h_idx[TOP6_MAX + 1];          // the hot records, unordered
@@ -249,9 +246,12 @@ __global__ __launch_bounds__(HS_SEL_THREADS) void k_select_hot(const PairRec* __
 
 // perm[i] = new index of record i: the hot records first (in index order among themselves), all others behind
 // them in index order; the visit counters zeroed for the next lamp.
-__global__ __launch_bounds__(256) void k_write_perm(const uint32_t* __restrict__ hot, uint32_t* __restrict__ perm,
-                                                    uint32_t* __restrict__ hist, int32_t n)
+__global__ __launch_bounds__(256) void k_write_perm(HotSetupParams p)
 {
+    const uint32_t* __restrict__ hot = p.hot_list + (size_t)blockIdx.y * (TOP6_MAX + 1);
+    uint32_t* __restrict__ perm = p.perm[blockIdx.y];
+    uint32_t* __restrict__ hist = p.hist + (size_t)blockIdx.y * (size_t)p.npairs;
+    const int32_t n = p.npairs;
     __shared__ uint32_t s_hot[TOP6_MAX + 1];
     const uint32_t H = hot[0] <= TOP6_MAX ? hot[0] : TOP6_MAX;
     for (uint32_t j = threadIdx.x; j < H; j += 256u) s_hot[j] = hot[1u + j];
@@ -268,33 +268,13 @@ __global__ __launch_bounds__(256) void k_write_perm(const uint32_t* __restrict__
     hist[i] = 0u;
 }
 
-void launch_visit_stats(const SceneDev& scene, uint32_t* hist, const float lamp[3], float light_length, uint32_t seed_prev,
-                        uint32_t seed_next, int32_t seed_mode, int32_t n, hipStream_t s)
+void launch_hot_setup(const HotSetupParams& p, hipStream_t s)
 {
-    if (n <= 0) return;
-    StatParams p;
-    p.pairs = scene.pairs;
-    p.ltris = scene.ltris;
-    p.leaf_count = scene.leaf_count;
-    p.hist = hist;
-    p.root_ref = scene.root_ref;
-    p.lx = lamp[0]; p.ly = lamp[1]; p.lz = lamp[2];
-    p.light_length = light_length;
-    p.seed_prev = seed_prev;
-    p.seed_next = seed_next;
-    p.seed_mode = seed_mode;
-    p.n = n;
-    hipLaunchKernelGGL(k_visit_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
-}
-
-void launch_select_hot(const PairRec* pairs, uint32_t* hist, uint32_t* hot_list, uint32_t* perm, int32_t npairs, int32_t keep,
-                       hipStream_t s)
-{
-    if (npairs <= 0) return;
-    if (keep > (int32_t)TOP6_MAX) keep = (int32_t)TOP6_MAX;
-    hipLaunchKernelGGL(k_select_hot, dim3(1), dim3(HS_SEL_THREADS), 0, s, pairs, (const uint32_t*)hist, hot_list, keep);
-    hipLaunchKernelGGL(k_write_perm, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, (const uint32_t*)hot_list, perm,
-                       hist, npairs);
+    if (p.count <= 0 || p.npairs <= 0 || p.n <= 0) return;
+    hipLaunchKernelGGL(k_visit_stats, dim3((unsigned)((p.n + 255) / 256), (unsigned)p.count), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_select_hot, dim3((unsigned)p.count), dim3(HS_SEL_THREADS), 0, s, p.pairs, (const uint32_t*)p.hist, p.hot_list,
+                       p.npairs, p.keep < (int32_t)TOP6_MAX ? p.keep : (int32_t)TOP6_MAX);
+    hipLaunchKernelGGL(k_write_perm, dim3((unsigned)((p.npairs + 255) / 256), (unsigned)p.count), dim3(256), 0, s, p);
 }
 
 }  // namespace uvrt
