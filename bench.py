@@ -118,13 +118,55 @@ def cpu_baseline(scene, route, waves, photons, flavour=0, budget_s=25.0):
     except Exception as e:      # reporting only
         ref_gpu = {"error": str(e)[:200]}
     orc.set_flavour(0)
+    ocl = opencl_cpu_devices()
     return {
+        "opencl_host_cpu_device": ("no OpenCL loader" if ocl is None else
+                                   "%d platform(s), %d CPU device(s)%s" % (ocl[0], ocl[1], "" if ocl[1] else
+                                                                            ": the reference's OpenCL path cannot run on the host CPU here; kind = port")),
         "reference_extend_cl_on_this_gpu": ref_gpu,
         "value": done * photons / total / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
         "sample": "%d of the step's %d waves x %d photons, lamp 0; generate is serial (defines the SEED "
                   "semantics), extend uses %d OpenMP threads; extend-only %.2f Mray/s"
                   % (done, waves, photons, cores, done * photons / t_ext / 1e6),
     }, tot, dose
+
+
+_OCL_PROBE = r"""
+import ctypes
+cl = None
+for name in ("libOpenCL.so.1", "libOpenCL.so", "/opt/rocm/lib/libOpenCL.so.1"):
+    try:
+        cl = ctypes.CDLL(name)
+        break
+    except OSError:
+        pass
+if cl is None:
+    print("none")
+else:
+    n = ctypes.c_uint(0)
+    cpus = 0
+    if cl.clGetPlatformIDs(0, None, ctypes.byref(n)) == 0 and n.value:
+        plats = (ctypes.c_void_p * n.value)()
+        cl.clGetPlatformIDs(n.value, plats, None)
+        for pl in plats:
+            m = ctypes.c_uint(0)
+            if cl.clGetDeviceIDs(ctypes.c_void_p(pl), ctypes.c_uint64(2), 0, None, ctypes.byref(m)) == 0:   # CL_DEVICE_TYPE_CPU
+                cpus += m.value
+    print(n.value, cpus)
+"""
+
+
+def opencl_cpu_devices():
+    """the north_star asks for the reference's OpenCL path on a host-CPU OpenCL device.  Enumerate what the
+    OpenCL ICD loader offers: (platforms, CPU devices); None when no loader can be opened.  Done in a child process (a
+    second runtime in this one is not worth a risk to the line).  ROCm's runtime has no CPU device, here or on the GPU
+    box; nothing is run either way -- the figure documents why the CPU baseline is the port."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", _OCL_PROBE], capture_output=True, text=True, timeout=30).stdout.split()
+        return (int(out[0]), int(out[1])) if len(out) == 2 else None
+    except Exception:
+        return None
 
 
 def soup_triangles(T, seed=1):
