@@ -99,6 +99,26 @@ def test_every_v6_variant_is_bit_exact_in_the_ocl_flavour(pkg, ctx, ctx_dev, orc
     _variant_case(ctx_dev if pkg.capi.needs_dev(variant) else ctx, orc, oscene, oroute, variant, 1)
 
 
+def test_product_library_holds_the_default_kernel_only(pkg, ctx, ctx_dev):
+    """Kernel knobs that select another instantiation (leaf periods 1 / 3 / 4, no LDS cache) exist in the developer
+    build only; grid and refill knobs of the default kernel are in both."""
+    for v in (400, 402, 405, 500, 606):
+        assert pkg.capi.needs_dev(v)
+        with pytest.raises(pkg.capi.UvrtError, match="developer build"):
+            ctx.set_variant(v)
+        ctx_dev.set_variant(v)
+    for v in (401, 451, 501, 601, 801):
+        assert not pkg.capi.needs_dev(v)
+        ctx.set_variant(v)
+        ctx_dev.set_variant(v)
+    for v in (1, 399, 900, 1208):
+        for c in (ctx, ctx_dev):
+            with pytest.raises(pkg.capi.UvrtError):
+                c.set_variant(v)
+    ctx.set_variant(0)
+    ctx_dev.set_variant(0)
+
+
 def _variant_case(ctx, orc, oscene, oroute, variant, flavour):
     n = 300000
     lp = lamp_pos(orc, oscene, oroute, 5)

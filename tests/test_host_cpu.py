@@ -104,10 +104,13 @@ def test_abi_exports_every_declared_symbol(pkg):
     declared.discard("uvrt_ctx")
     bound = {name for name, _, _ in pkg.capi.SYMBOLS}
     assert declared == bound, declared ^ bound
-    L = ctypes.CDLL(pkg.capi.LIB_PATH)
-    for name in declared:
-        assert hasattr(L, name), name
-    assert b"gfx950" in pkg.capi.lib().uvrt_version()
+    for path in (pkg.capi.LIB_PATH, pkg.capi.LIB_DEV_PATH):      # the product and the developer build of the same sources
+        L = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(L, name), (path, name)
+    assert b"gfx950" in pkg.capi.lib().uvrt_version() and b"gfx950" in pkg.capi.lib(dev=True).uvrt_version()
+    # the product library is the smaller one: it holds the default traversal kernel only
+    assert os.path.getsize(pkg.capi.LIB_PATH) < os.path.getsize(pkg.capi.LIB_DEV_PATH)
 
 
 def test_replay_op_binding_matches_the_header(pkg, tmp_path):
