@@ -63,7 +63,8 @@ namespace uvrt_impl {
 // workgroups to XCDs stays balanced.
 int set_lane_cu_mask(uvrt_ctx* c, int reserve)
 {
-    if (reserve < 0 || reserve % 8 != 0 || reserve >= c->num_cus) reserve = 0;
+    // the mask layout was probed on the whole MI355X (256 CUs, 8 XCDs); a partitioned device keeps its plain streams
+    if (reserve < 0 || reserve % 8 != 0 || c->num_cus != 256) reserve = 0;
     if (reserve == c->lanes_masked_cus) return UVRT_OK;
     if (int rc = set_device(c)) return rc;
     if (int rc = join_all(c)) return rc;
