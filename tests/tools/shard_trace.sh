@@ -27,9 +27,11 @@ prev=None; waits=[]; durs=[]
 for r in rows:
     n=r["Kernel_Name"]
     if "k_fold_planes" in n: prev=int(r["End_Timestamp"])
-    elif ("ccl" in n.lower() or "AllReduce" in n) and prev is not None:
+    elif ("nccl" in n.lower() or "AllReduce" in n) and prev is not None:
         waits.append((int(r["Start_Timestamp"])-prev)/1e3); durs.append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3); prev=None
-if waits:
+if not waits:
+    print("no RCCL kernel in the trace (a one-rank communicator launches none for an in-place all-reduce)")
+else:
     waits.sort(); durs.sort()
     print("all-reduce kernel: %d launches; start after its fold: median %.1f us, p90 %.1f us; duration median %.1f us, p90 %.1f us" % (len(waits), waits[len(waits)//2], waits[int(len(waits)*0.9)], durs[len(durs)//2], durs[int(len(durs)*0.9)]))
 PY
