@@ -197,7 +197,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.recs = c->b_recs[g].p;
             p.perm = gperm[g];
             p.recs_prepared = 1;
-            p.refill_min = variant_refill_min(c->variant);
+            p.refill_min = variant_refill_min(c->variant, (size_t)c->npairs + (size_t)c->T);
             p.plane_batches = (uint32_t)(n_pad / 64);
             p.plane_n = (uint32_t)n;
             p.plane_stride = (uint32_t)plane_ints;

@@ -324,7 +324,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         return UVRT_OK;
     }
     if (c->variant >= 500 && c->variant < 600) p.force_exact = 1;
-    p.refill_min = variant_refill_min(c->variant);
+    p.refill_min = variant_refill_min(c->variant, (size_t)c->npairs + (size_t)c->T);
     // default grid: 8 workgroups per CU on one stream (20 KB of LDS each: eight fit a CU); 7 when launches are
     // pipelined over several streams -- the free slot per CU lets the first workgroups of the next launch and the
     // small kernels around it (generate, accumulate, replay) run at once instead of queueing behind persistent waves

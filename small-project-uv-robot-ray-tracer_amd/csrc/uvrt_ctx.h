@@ -314,7 +314,14 @@ inline int auto_sort_bits(int64_t n)
 
 
 inline bool variant_is_knob(int v) { return v >= 400 && v < 900; }
-inline int variant_refill_min(int v) { return !variant_is_knob(v) ? 8 : v >= 800 ? 4 : v >= 700 ? 24 : v >= 600 ? 8 : 16; }
+// idle lanes that trigger a refill.  Default 8; 24 for scenes of a million records and more, where a trip is a miss to the
+// fabric whatever its lanes do and fewer, fuller refills are worth 2-3 % (profiles/r03_soup_knobs.txt; the room is flat
+// between 8 and 16 and loses at 24)
+inline int variant_refill_min(int v, size_t records)
+{
+    if (!variant_is_knob(v)) return records >= ((size_t)1 << 20) ? 24 : 8;
+    return v >= 800 ? 4 : v >= 700 ? 24 : v >= 600 ? 8 : 16;
+}
 inline int variant_code6(int v) { return !variant_is_knob(v) ? 1 : v % 10; }   // default: LDS top cache, leaf period 2
 inline int variant_per_cu(int v, int dflt)
 {
