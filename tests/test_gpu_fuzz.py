@@ -31,7 +31,10 @@ def random_scene(rng):
     return tris, extent
 
 
-CASES = list(range(64))
+import os
+
+# UVRT_FUZZ_CASES=N widens the sweep (a soak run: 600 cases take about a minute on the GPU box)
+CASES = list(range(int(os.environ.get("UVRT_FUZZ_CASES", "64"))))
 
 
 @pytest.mark.parametrize("case", CASES)
