@@ -32,7 +32,8 @@ constexpr int HS_LDS_BINS = 8192;     // visit counters kept in LDS by k_visit_s
 constexpr int HS_QUEUE = 16;          // visits to deeper records a lane collects in LDS before the wave flushes them
 constexpr int HS_CAND = 4096;         // candidate records of k_select_hot
 constexpr int HS_EQ = 1024;           // candidates AT the threshold that take part in the tie-break by index
-constexpr int HS_MAX_STEPS = 64;      // traversal steps of a sample ray that are counted (99 % of the test room's rays take fewer)
+constexpr int HS_MAX_STEPS = 128;     // traversal steps of a sample ray that are counted at most
+constexpr int HS_TAIL_LANES = 6;      // a wave stops once no more than this many of its 64 rays are still under way (after 32 steps)
 
 // Several lamps' set-ups in one launch of each kernel (uvrt_device.h HotSetupParams): blockIdx.y = the lamp.
 typedef HotSetupParams StatParams;
@@ -81,9 +82,11 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     // One step per trip, ONE memory round trip per step: the 64 bytes at the lane's record -- a node-pair record or a
     // leaf triangle (48 bytes; the 16 behind it are the next triangle's or the buffer's padding).  Deep records are
     // cold by definition, so every trip of a wave waits for a miss to HBM: the kernel lasts (steps of the slowest
-    // ray) x (miss latency + the step's ~150 instructions at one wave per SIMD), and rays are cut off after HS_MAX_STEPS steps (1 % of the test room's rays take more;
-    // what they would still visit does not change which records are hot).
+    // ray) x (miss latency + the step's ~150 instructions at one wave per SIMD).  So a wave does not wait for its
+    // stragglers: it stops when at most HS_TAIL_LANES of its rays are still under way (the slowest tenth of the rays
+    // takes half as many steps again as the rest; what those would still visit does not change which records are hot).
     for (int it = 0; it < HS_MAX_STEPS && cur != REF_DONE; ++it) {
+        if (it >= 32 && __popcll(__builtin_amdgcn_ballot_w64(true)) <= HS_TAIL_LANES) break;     // (the lanes still in the loop)
         const bool leaf = cur >= REF_LEAF_BIT;
         const uint32_t first = cur & REF_FIRST_MASK;
         const float4* src = leaf ? (const float4*)(p.ltris + first) : (const float4*)(p.pairs + cur);
