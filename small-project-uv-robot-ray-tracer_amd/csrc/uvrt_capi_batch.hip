@@ -115,7 +115,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             c->b_recs.push_back(b);
         }
         c->b_recs_key.resize(c->b_recs.size());
-        for (int l = 1; l <= 2; ++l)
+        for (int l = 1; l <= c->batch_lanes; ++l)
             if ((rc = c->xovf[l].ensure((size_t)c->num_cus * 8 * 256 * 24 * sizeof(uint32_t), false, c->stream))) return rc;
     }
     if (need_alloc || recs_stale) {
@@ -142,7 +142,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             const int kc = std::min(per_chunk, gsize[g] - k0), ph0 = gfirst[g] + k0;
             // two SIDE lanes in turn: the context's own stream carries the fold / reduce / replay of the previous batch,
             // which a chunk enqueued there would have to wait for
-            c->lane = c->pipeline ? 1 + (int)(c->b_chunks++ & 1u) : 0;
+            c->lane = c->pipeline ? 1 + (int)(c->b_chunks++ % (uint64_t)c->batch_lanes) : 0;
             // the chunk's rays depend on nothing but their buffer: generate goes to the lane BEFORE the lane waits for the
             // context's stream (new records, a hot-record set-up), so it runs beside them
             hipStream_t ls = stream_of(c, c->lane);

@@ -146,6 +146,7 @@ struct uvrt_ctx {
     BatchSet bs[2];
     int b_set = 0;                        // the set of the traced batch (b_count > 0) / of the last one
     uint64_t b_chunks = 0;                // chunks traced so far: consecutive chunks alternate over the launch lanes
+    int batch_lanes = 2;                  // side lanes the chunks of a batch alternate over (developer knob UVRT_BATCH_LANES: 1..3)
     int32_t b_repl = 16;                  // deposit replicas per plane of the traced batch
     std::vector<DevBuf> b_recs;           // [group]
     struct RecsKey { float ox = 0, oz = 0; const uint32_t* perm = nullptr; bool valid = false; };
