@@ -75,6 +75,8 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     if (const char* e = getenv("UVRT_BATCH_LANES")) { const int v = atoi(e); if (v >= 1 && v <= uvrt_ctx::MAXL - 1) c->batch_lanes = v; }
     if (const char* e = getenv("UVRT_COMM_RESERVE_CUS")) { const int v = atoi(e); if (v >= 0 && v <= 64 && v % 8 == 0) c->comm_reserve_knob = v; }
     if (const char* e = getenv("UVRT_HOT_SAMPLE")) { const int v = atoi(e); if (v >= 256 && v <= (1 << 20)) c->hot_sample = v; }
+    if (const char* e = getenv("UVRT_HOT_DIRECT")) { const int v = atoi(e); if (v >= 0 && v <= 8192) c->hot_direct = v; }
+    if (const char* e = getenv("UVRT_HOT_TAIL")) { const int v = atoi(e); if (v >= 0 && v < 64) c->hot_tail = v; }
     int rc = c->error_flag.ensure(256, true, c->stream);      // the flag; a developer build keeps trip statistics behind it
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
     if (!rc) rc = c->ovf_stack.ensure((size_t)OVF_MAX_ENTRIES * sizeof(uint32_t), false, c->stream);

@@ -88,6 +88,8 @@ int hot_build(uvrt_ctx* c, uvrt_ctx::HotEntry* const* entries, const uint32_t* s
         // the statistics always sample global ids [0, hot_sample) of the lamp (the kernel makes its own rays), whichever
         // range of the launch this context traces
         p.n = c->hot_sample;
+        p.tail_lanes = c->hot_tail;
+        p.direct_bins = c->hot_direct;
         p.npairs = c->npairs;
         p.keep = (int32_t)TOP6_MAX;
         p.count = kc;

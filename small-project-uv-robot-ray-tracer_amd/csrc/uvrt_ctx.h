@@ -134,6 +134,8 @@ struct uvrt_ctx {
     std::vector<DevBuf> hot_slabs;        // [ceil(entries / HOT_SLAB)]: HOT_SLAB x npairs uint32 each
     DevBuf hot_hist[MAXL], hot_list[MAXL];
     int32_t hot_sample = 32768;           // photons of the launch whose visits are counted (developer knob UVRT_HOT_SAMPLE)
+    int32_t hot_direct = 8192;            // records k_select_hot takes as candidates without a tree walk (developer knob UVRT_HOT_DIRECT; tests force the walk with it)
+    int32_t hot_tail = 16;                // straggler rule of k_visit_stats (developer knob UVRT_HOT_TAIL, uvrt_hotset.hip)
     uint64_t hot_clock = 0;
     int32_t hot_mode = 1;                 // uvrt_set_hot_records: 1 = automatic (default), 0 = breadth-first order
     const uint32_t* lane_perm[MAXL] = {}; // renumbering of the current launch of each lane (set by uvrt_generate)

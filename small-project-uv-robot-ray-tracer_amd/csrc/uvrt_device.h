@@ -258,6 +258,8 @@ struct HotSetupParams {
     int32_t seed_mode;
     int32_t n;                         // photons of the launch whose visits are counted (global ids [0, n))
     int32_t npairs, keep, count;       // records, hot records wanted, lamps
+    int32_t tail_lanes;                // a wave of k_visit_stats stops once at most this many of its rays are under way
+    int32_t direct_bins;               // k_select_hot looks for the hot records among the first direct_bins records before it walks the tree
     uint32_t* hist;                    // [count][npairs] visit counters: zero before, zero again after
     uint32_t* hot_list;                // [count][TOP6_MAX + 1] scratch: number of hot records + their indices, ascending
     uint32_t* perm[HS_GROUPS];         // out: the renumbering of lamp k, [npairs]

@@ -33,7 +33,6 @@ constexpr int HS_QUEUE = 16;          // visits to deeper records a lane collect
 constexpr int HS_CAND = 4096;         // candidate records of k_select_hot
 constexpr int HS_EQ = 1024;           // candidates AT the threshold that take part in the tie-break by index
 constexpr int HS_MAX_STEPS = 128;     // traversal steps of a sample ray that are counted at most
-constexpr int HS_TAIL_LANES = 6;      // a wave stops once no more than this many of its 64 rays are still under way (after 32 steps)
 
 // Several lamps' set-ups in one launch of each kernel (uvrt_device.h HotSetupParams): blockIdx.y = the lamp.
 typedef HotSetupParams StatParams;
@@ -49,15 +48,19 @@ __device__ __forceinline__ bool box_approx(float mnx, float mny, float mnz, floa
     return tmax >= tmin && tmin < dist && tmax > 0;
 }
 
-__global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
+// (Workgroups of 128 or 64 threads, spread over twice / four times as many CUs, are no faster: 98 / 106 us against 97 us --
+// the kernel lasts as long as the dependent fetches of its longest rays, profiles/r03_hot_setup_sweep.txt.)
+constexpr int HS_THREADS = 256;
+__global__ __launch_bounds__(HS_THREADS) void k_visit_stats(StatParams p)
 {
+    constexpr int NT = HS_THREADS;
     __shared__ uint32_t s_hist[HS_LDS_BINS];      // 32 KB
-    __shared__ uint32_t s_stack[32][256];         // 32 KB: entry e of thread t at [e][t] (conflict-free)
-    __shared__ uint32_t s_queue[HS_QUEUE][256];   // 16 KB: deep records visited by thread t, not yet counted
+    __shared__ uint32_t s_stack[32][NT];          // 32 KB: entry e of thread t at [e][t] (conflict-free)
+    __shared__ uint32_t s_queue[HS_QUEUE][NT];    // 16 KB: deep records visited by thread t, not yet counted
     const int tid = threadIdx.x;
-    for (int i = tid; i < HS_LDS_BINS; i += 256) s_hist[i] = 0u;
+    for (int i = tid; i < HS_LDS_BINS; i += NT) s_hist[i] = 0u;
     __syncthreads();
-    const int gid = blockIdx.x * 256 + tid;
+    const int gid = blockIdx.x * NT + tid;
     const int grp = blockIdx.y;                                       // the lamp of this workgroup
     uint32_t* const hist = p.hist + (size_t)grp * (size_t)p.npairs;
     uint32_t cur = (gid < p.n && p.root_ref < REF_LEAF_BIT) ? p.root_ref : REF_DONE;
@@ -83,10 +86,12 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     // leaf triangle (48 bytes; the 16 behind it are the next triangle's or the buffer's padding).  Deep records are
     // cold by definition, so every trip of a wave waits for a miss to HBM: the kernel lasts (steps of the slowest
     // ray) x (miss latency + the step's ~150 instructions at one wave per SIMD).  So a wave does not wait for its
-    // stragglers: it stops when at most HS_TAIL_LANES of its rays are still under way (the slowest tenth of the rays
-    // takes half as many steps again as the rest; what those would still visit does not change which records are hot).
+    // stragglers: it stops when at most p.tail_lanes of its rays are still under way (16 of 64: the slowest quarter of the
+    // rays takes half as many steps again as the rest; what those would still visit does not change which records are hot --
+    // coverage of the true best 175 over the route's 12 lamps 0.9989-0.9999 with 16, 0.9994-0.9999 with 6, and 10 % less
+    // time; profiles/r03_hot_setup_sweep.txt).
     for (int it = 0; it < HS_MAX_STEPS && cur != REF_DONE; ++it) {
-        if (it >= 32 && __popcll(__builtin_amdgcn_ballot_w64(true)) <= HS_TAIL_LANES) break;     // (the lanes still in the loop)
+        if (it >= 32 && __popcll(__builtin_amdgcn_ballot_w64(true)) <= p.tail_lanes) break;     // (the lanes still in the loop)
         const bool leaf = cur >= REF_LEAF_BIT;
         const uint32_t first = cur & REF_FIRST_MASK;
         const float4* src = leaf ? (const float4*)(p.ltris + first) : (const float4*)(p.pairs + cur);
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
     }
     flush_queue();
     __syncthreads();
-    for (int i = tid; i < HS_LDS_BINS; i += 256) {
+    for (int i = tid; i < HS_LDS_BINS; i += NT) {
         const uint32_t v = s_hist[i];
         if (v) atomicAdd(&hist[i], v);            // only bins below npairs are ever counted
     }
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void k_visit_stats(StatParams p)
 // hot[0] = H (number of hot records, <= keep), hot[1 .. H] = their indices in ascending order.  One workgroup.
 constexpr int HS_SEL_THREADS = 256;
 __global__ __launch_bounds__(HS_SEL_THREADS) void k_select_hot(const PairRec* __restrict__ pairs, const uint32_t* __restrict__ hist_all,
-                                                             uint32_t* __restrict__ hot_all, int32_t npairs, int32_t keep)
+                                                             uint32_t* __restrict__ hot_all, int32_t npairs, int32_t keep, int32_t direct_bins)
 {
     const uint32_t* __restrict__ hist = hist_all + (size_t)blockIdx.x * (size_t)npairs;      // one workgroup per lamp
     uint32_t* __restrict__ hot = hot_all + (size_t)blockIdx.x * (TOP6_MAX + 1);
@@ -155,22 +160,44 @@ __global__ __launch_bounds__(HS_SEL_THREADS) void k_select_hot(const PairRec* __
     const int tid = threadIdx.x;
     constexpr uint32_t NT = HS_SEL_THREADS;
     const uint32_t root_cnt = hist[0];                // every sampled ray visits the root (pair record 0)
+    // The counters of the first direct_bins records, HS_LDS_BINS / NT per thread in registers (one coalesced read): most of
+    // the hot records lie among them, and there no tree walk is needed -- any record whose count reaches the floor is a
+    // candidate (the counts themselves make the selection a subtree).  Only the part of the subtree that reaches beyond
+    // them is walked, from the candidates whose children lie there (every other lamp of the test room has such a part).
+    const uint32_t nd = (uint32_t)npairs < (uint32_t)direct_bins ? (uint32_t)npairs : (uint32_t)direct_bins;      // direct_bins <= HS_LDS_BINS
+    uint32_t mine[HS_LDS_BINS / HS_SEL_THREADS];
+#pragma unroll
+    for (int k = 0; k < HS_LDS_BINS / HS_SEL_THREADS; ++k) {
+        const uint32_t j = (uint32_t)k * NT + (uint32_t)tid;
+        mine[k] = j < nd ? hist[j] : 0u;
+    }
     // the floor a record's count must reach to become a candidate; lowered if it leaves fewer than `keep`
     uint32_t floor_cnt = root_cnt >> 6;
     if (floor_cnt < 1u) floor_cnt = 1u;
     uint32_t M;
     for (;;) {
         __syncthreads();
-        if (tid == 0) { c_idx[0] = 0u; c_cnt[0] = root_cnt; s_n = 1u; s_begin = 0u; s_end = 1u; }
+        if (tid == 0) { c_idx[0] = 0u; c_cnt[0] = root_cnt; s_n = nd ? 0u : 1u; }
         __syncthreads();
-        for (;;) {                                    // one tree level of the hot subtree per round
+#pragma unroll
+        for (int k = 0; k < HS_LDS_BINS / HS_SEL_THREADS; ++k) {
+            if (mine[k] < floor_cnt) continue;            // (mine[] is 0 beyond nd, floor_cnt >= 1)
+            const uint32_t slot = atomicAdd(&s_n, 1u);
+            if (slot < (uint32_t)HS_CAND) { c_idx[slot] = (uint32_t)k * NT + (uint32_t)tid; c_cnt[slot] = mine[k]; }
+        }
+        __syncthreads();
+        if (tid == 0) { s_begin = 0u; s_end = s_n < (uint32_t)HS_CAND ? s_n : (uint32_t)HS_CAND; s_n = s_end; }
+        __syncthreads();
+        // the part of the hot subtree beyond the first nd records, one tree level per round (with nd = 0: the whole walk
+        // from the root): children at indices >= nd whose count reaches the floor
+        for (;;) {
             const uint32_t b = s_begin, e = s_end;
-            if (b >= e) break;
+            if (b >= e || (uint32_t)npairs <= nd) break;
             for (uint32_t j = b + tid; j < e; j += NT) {
                 const PairRec* pr = pairs + c_idx[j];
                 const uint32_t r[2] = {__float_as_uint(pr->c0min_ref0.w), __float_as_uint(pr->c0max_ref1.w)};
                 for (int k = 0; k < 2; ++k) {
-                    if (r[k] >= REF_LEAF_BIT) continue;
+                    if (r[k] >= REF_LEAF_BIT || r[k] < nd) continue;
                     const uint32_t c = hist[r[k]];
                     if (c < floor_cnt) continue;
                     const uint32_t slot = atomicAdd(&s_n, 1u);
@@ -239,10 +266,10 @@ __global__ __launch_bounds__(HS_SEL_THREADS) void k_select_hot(const PairRec* __
     __syncthreads();
     const uint32_t H = n_above + (n_eq < room ? n_eq : room);
     for (uint32_t j = tid; j < H; j += NT) {
-        const uint32_t mine = h_idx[j];
+        const uint32_t mine_idx = h_idx[j];
         uint32_t before = 0u;
-        for (uint32_t k = 0; k < H; ++k) before += h_idx[k] < mine;
-        hot[1u + before] = mine;
+        for (uint32_t k = 0; k < H; ++k) before += h_idx[k] < mine_idx;
+        hot[1u + before] = mine_idx;
     }
     if (tid == 0) hot[0] = H;
 }
@@ -274,9 +301,10 @@ __global__ __launch_bounds__(256) void k_write_perm(HotSetupParams p)
 void launch_hot_setup(const HotSetupParams& p, hipStream_t s)
 {
     if (p.count <= 0 || p.npairs <= 0 || p.n <= 0) return;
-    hipLaunchKernelGGL(k_visit_stats, dim3((unsigned)((p.n + 255) / 256), (unsigned)p.count), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_visit_stats, dim3((unsigned)((p.n + HS_THREADS - 1) / HS_THREADS), (unsigned)p.count), dim3(HS_THREADS), 0, s, p);
     hipLaunchKernelGGL(k_select_hot, dim3((unsigned)p.count), dim3(HS_SEL_THREADS), 0, s, p.pairs, (const uint32_t*)p.hist, p.hot_list,
-                       p.npairs, p.keep < (int32_t)TOP6_MAX ? p.keep : (int32_t)TOP6_MAX);
+                       p.npairs, p.keep < (int32_t)TOP6_MAX ? p.keep : (int32_t)TOP6_MAX,
+                       p.direct_bins < 0 ? 0 : p.direct_bins < HS_LDS_BINS ? p.direct_bins : HS_LDS_BINS);
     hipLaunchKernelGGL(k_write_perm, dim3((unsigned)((p.npairs + 255) / 256), (unsigned)p.count), dim3(256), 0, s, p);
 }
 

@@ -67,6 +67,33 @@ def test_hot_records_are_the_most_visited_ones(pkg, orc, oscene, oroute, lamp, s
         c.close()
 
 
+def test_selection_with_and_without_the_tree_walk(pkg, orc, oscene, oroute, monkeypatch):
+    """k_select_hot looks for the hot records among the first 8192 records and walks the tree from the root only when a
+    record beyond them belongs to the set (frontier check).  Forced through the developer knob UVRT_HOT_DIRECT (read in
+    uvrt_create): no direct candidates at all, 64 of them (the check must fire: the hot records reach beyond 64), and
+    the default -- one and the same renumbering."""
+    P = pair_order(oscene.nodes).size
+    lp = lamp_pos(orc, oscene, oroute, 4)
+    perms = []
+    for direct in (None, "0", "64", "1000"):
+        if direct is None:
+            monkeypatch.delenv("UVRT_HOT_DIRECT", raising=False)
+        else:
+            monkeypatch.setenv("UVRT_HOT_DIRECT", direct)
+        c = pkg.capi.Ctx(0)
+        try:
+            c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+            c.resize_rays(65536)
+            c.seed = 99
+            c.generate(lp, oroute["lightLength"], 0, 65536)
+            perms.append(c.read_record_perm(P))
+        finally:
+            c.close()
+    assert np.flatnonzero(perms[0] < KEEP).size == KEEP
+    for q in perms[1:]:
+        assert np.array_equal(q, perms[0])
+
+
 def test_more_lamp_positions_than_cache_entries(pkg, orc, oscene, oroute):
     """70 lamp positions through the 64-entry cache of renumberings (least recently used entries are rebuilt): counts
     of the last launches still equal the oracle's."""
