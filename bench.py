@@ -335,11 +335,30 @@ def main():
 
     # ---- the sharded (strong) computation: ray ranges + one collective per batch ---------------------------
     native_comm = False
+    comm_note = ""
     if world > 1 and not rehearsal:
-        ids = [capi.comm_unique_id() if rank == 0 else None]
+        # the context's own RCCL communicator (uvrt_comm_init_rank); should it fail on ANY rank, every rank reduces the
+        # planes with torch.distributed's RCCL all-reduce on the device instead (same collective, one more host call)
+        ok, why = 1, ""
+        try:
+            ids = [capi.comm_unique_id() if rank == 0 else None]
+        except Exception as e:          # noqa: BLE001  (reported in the line)
+            ids, ok, why = [None], 0, str(e)
         dist.broadcast_object_list(ids, src=0)
-        rt.ctx.comm_init_rank(ids[0], rank, world)
-        native_comm = True
+        if ok and ids[0] is not None:
+            try:
+                rt.ctx.comm_init_rank(ids[0], rank, world)
+            except Exception as e:      # noqa: BLE001
+                ok, why = 0, str(e)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native_comm = bool(int(flag.item()))
+        if not native_comm:
+            if ok:
+                rt.ctx.comm_destroy()
+            comm_note = "native communicator unavailable (%s): torch.distributed RCCL all-reduce of the planes" % (why or "another rank failed")
     if args.self_comm:
         if world != 1 or args.mode != "batched":
             raise SystemExit("--self-comm is the N = 1 rehearsal of the batched, sharded step")
@@ -352,7 +371,18 @@ def main():
     def step_batched():
         rt.ctx.seed = 0                       # every step is the same computation (fresh-Init SEED)
         rt.ResetDosageMap()
-        if world > 1 and rehearsal:
+        if world > 1 and not rehearsal and not native_comm:
+            # the same step with torch.distributed's RCCL all-reduce of the device planes (the stream is torch's current one)
+            ops = np.zeros(args.waves, dtype=capi.REPLAY_OP_DT)
+            for k in range(args.waves):
+                ops[k] = (lamp[2], 1, 0, (k + 1) * n_launch, float(np.float32(rt.lightIntensity) * np.float32(0.1)),
+                          rt.minDosage, 0)
+            rt.ctx.trace_batch([lp] * args.waves, rt.lightLength, first, mine)
+            dist.all_reduce(sharding.wrap_array(rt.ctx, 5, device, "<i4"), op=dist.ReduceOp.SUM)
+            rt.ctx.replay_batch(ops)
+            rt.photonMapSize = args.waves * n_launch
+            rt.currIterations = args.waves
+        elif world > 1 and rehearsal:
             # ranks share a GPU: RCCL wants one rank per device, so the planes go through gloo (test path only)
             ops = np.zeros(args.waves, dtype=capi.REPLAY_OP_DT)
             for k in range(args.waves):
@@ -557,7 +587,8 @@ def main():
         strong = {"value": round(rays_per_step * args.steps / el_s / 1e6, 2), "unit": "Mray/s",
                   "ms_per_step": round(el_s / args.steps * 1e3, 4), "rays_per_step": rays_per_step, "scaling": "strong",
                   "parallelism": "ray-range-sharded x%d, one int32 all-reduce of the count planes per computation (%s)"
-                                 % (world, "native RCCL, uvrt_reduce_batch" if native_comm else "REHEARSAL: ranks share a GPU, gloo"),
+                                 % (world, "native RCCL, uvrt_reduce_batch" if native_comm else
+                                    "REHEARSAL: ranks share a GPU, gloo" if rehearsal else comm_note),
                   "dose_crc32": crc(dose_s)}
         # weak: configs[4], same run
         rt.SetRayRange(0, 1)

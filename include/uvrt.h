@@ -219,7 +219,7 @@ int uvrt_set_pipeline(uvrt_ctx* ctx, int32_t on);
 
 /* extend kernel knobs (developer / A-B; every setting is bit-exact): 0 = default; 400-499 = leaf period /
  * LDS top cache code + 10 * grid code with refill at 16 idle lanes; 500-599 = the same with IEEE divisions
- * everywhere; 600-899 = like 400-499 with the refill threshold 8 / 24 / 4 idle lanes.  See DESIGN.md 4. */
+ * everywhere; 600-1299 = like 400-499 with the refill threshold 8 / 24 / 4 / 32 / 40 / 48 / 56 idle lanes.  See DESIGN.md 4. */
 int uvrt_set_variant(uvrt_ctx* ctx, int32_t variant);
 
 /* ---- test / interop hooks ---- */

@@ -579,7 +579,7 @@ int uvrt_set_variant(uvrt_ctx* c, int32_t variant)
 {
     if (!c) return fail(UVRT_ERR_INVALID, "null context");
     if (!variant_ok(variant))
-        return fail(UVRT_ERR_INVALID, "uvrt_set_variant: %d is not a variant of this build (0, 400-899; codes other than 1 in the "
+        return fail(UVRT_ERR_INVALID, "uvrt_set_variant: %d is not a variant of this build (0, 400-1299; codes other than 1 in the "
                     "last digit need the developer build libuvrt_hip_dev.so)", variant);
     c->variant = variant;
     return UVRT_OK;

@@ -297,13 +297,13 @@ inline void split_bits(int bits, int& bphi, int& by, int& bo)
 // Kernel knobs (uvrt_set_variant).  0 (default) = the top-of-tree LDS cache, leaf visits every second
 // trip, refill at 8 idle lanes, 8 workgroups per CU; 400-499 = code + 10 * grid code (uvrt_extend6.hip:
 // code bits 0-1 leaf period - 1, bit 2 no LDS cache; grid code 0..4 = 8 / 4 / 6 / 2 / 16 workgroups per CU)
-// with refill at 16 idle lanes; 500-599 = the same with IEEE divisions everywhere; 600-899 = like 400-499
-// with the refill threshold 8 / 24 / 4 idle lanes.  (The v1-v5 kernels of round 1 are gone: see git history
+// with refill at 16 idle lanes; 500-599 = the same with IEEE divisions everywhere; 600-1299 = like 400-499 with the refill threshold 8 / 24 / 4 / 32 / 40 / 48 / 56 idle
+// lanes (hundreds digit 6 ... 12).  (The v1-v5 kernels of round 1 are gone: see git history
 // and DESIGN.md section 4 for what they measured.)
 #ifdef UVRT_DEV_VARIANTS
-inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900); }
+inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 1300); }
 #else      // the product library holds the default kernel only: code 1 (leaf period 2, LDS cache) with any grid / refill knob
-inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 900 && v % 10 == 1); }
+inline bool variant_ok(int v) { return v == 0 || (v >= 400 && v < 1300 && v % 10 == 1); }
 #endif
 
 inline int auto_sort_bits(int64_t n)
@@ -316,14 +316,14 @@ inline int auto_sort_bits(int64_t n)
 }
 
 
-inline bool variant_is_knob(int v) { return v >= 400 && v < 900; }
+inline bool variant_is_knob(int v) { return v >= 400 && v < 1300; }
 // idle lanes that trigger a refill.  Default 8; 24 for scenes of a million records and more, where a trip is a miss to the
 // fabric whatever its lanes do and fewer, fuller refills are worth 2-3 % (profiles/r03_soup_knobs.txt; the room is flat
 // between 8 and 16 and loses at 24)
 inline int variant_refill_min(int v, size_t records)
 {
     if (!variant_is_knob(v)) return records >= ((size_t)1 << 20) ? 24 : 8;
-    return v >= 800 ? 4 : v >= 700 ? 24 : v >= 600 ? 8 : 16;
+    return v >= 1200 ? 56 : v >= 1100 ? 48 : v >= 1000 ? 40 : v >= 900 ? 32 : v >= 800 ? 4 : v >= 700 ? 24 : v >= 600 ? 8 : 16;
 }
 inline int variant_code6(int v) { return !variant_is_knob(v) ? 1 : v % 10; }   // default: LDS top cache, leaf period 2
 inline int variant_per_cu(int v, int dflt)

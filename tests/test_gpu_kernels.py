@@ -107,11 +107,11 @@ def test_product_library_holds_the_default_kernel_only(pkg, ctx, ctx_dev):
         with pytest.raises(pkg.capi.UvrtError, match="developer build"):
             ctx.set_variant(v)
         ctx_dev.set_variant(v)
-    for v in (401, 451, 501, 601, 801):
+    for v in (401, 451, 501, 601, 801, 901, 1251):
         assert not pkg.capi.needs_dev(v)
         ctx.set_variant(v)
         ctx_dev.set_variant(v)
-    for v in (1, 399, 900, 1208):
+    for v in (1, 399, 1300, 2208):
         for c in (ctx, ctx_dev):
             with pytest.raises(pkg.capi.UvrtError):
                 c.set_variant(v)
