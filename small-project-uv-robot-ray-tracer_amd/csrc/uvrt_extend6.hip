@@ -281,6 +281,9 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
 //  * a one-dword load past L1 (sc1) of a pushed child's record at the push -- a pushed node IS visited later,
 //    extend.cl:77-79 -- into the one dead register of the record window, v55: -10.7 % on the room, -2.9 % on a
 //    6 M-triangle soup beyond every cache.
+//  * run-ahead of the lanes at cached records while the trip's global loads are in flight (their own copies of the record
+//    window under exec = those lanes, repeated while they keep landing on cached records): -4 % on a 6 M-triangle soup, -25 % on
+//    a 1 M one, -63 % on the room (profiles/r03_run_ahead.patch): with 28 waves per CU one wave's wait is the others' issue time.
 // Arithmetic: slabs / boxes / hit tests are step7's (slabs6, box2_fast, the v_cmpx tail); the triangle test is
 // tri6<OCL> instruction for instruction (extend.cl:6-27), early returns as v_cmpx narrowing of exec.
 // A kernel with this stream must not spill: scratch use costs the launch pipelining 14 % (measured); the general
