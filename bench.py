@@ -521,14 +521,22 @@ def main():
                     raise SystemExit("bench: seed-mode-1 / flavour-1 dose CRC %s differs from the oracle's %s" % (crc_r, exp_r))
             # ---- a lamp position the context has never seen: the hot-record set-up (uvrt_hotset.hip) is inside ------
             if len(all_lamps) > 1 and not args.route:
-                configure(all_lamps[1:2], args.photons, args.waves)
-                cold_ms = one_synced(headline)
+                # five positions next to lamp 1 of the route, none of them seen before (and none a lamp of the route, whose own
+                # cold figure follows below): each first computation is a cold start; the median guards against a one-off
+                base = all_lamps[1]
+                colds = []
+                for k in range(1, 6):
+                    configure([(base[0] + 0.015625 * k, base[1] - 0.015625 * k, base[2])], args.photons, args.waves)
+                    colds.append(one_synced(headline))
+                cold_ms = float(np.median(colds))
                 warm_ms = median_synced(headline, few)
                 cold = {"new_lamp_first_computation_ms": round(cold_ms, 4), "same_lamp_warm_ms": round(warm_ms, 4),
-                        "cold_over_warm": round(cold_ms / warm_ms, 4), "mode": args.mode,
-                        "note": "lamp 1 of the route, first computation at a lamp position the context has not seen (visit "
-                                "statistics + hot-record selection + renumbering + per-launch records inside), against the median "
-                                "of the next %d at the same lamp; each bracketed by device syncs; buffers already allocated" % few}
+                        "cold_over_warm": round(cold_ms / warm_ms, 4), "new_lamp_samples_ms": [round(v, 4) for v in colds],
+                        "mode": args.mode,
+                        "note": "median over 5 lamp positions the context has not seen (next to lamp 1 of the route): the first "
+                                "computation at each (visit statistics + hot-record selection + renumbering + per-launch records "
+                                "inside), against the median of the next %d at the last of them; each bracketed by device syncs; "
+                                "buffers already allocated" % few}
                 configure(headline_lamps, args.photons, args.waves)
         # ---- the reference's default workload: 12 lamps x 10 iterations x 2 796 202 photons -----------------------
         if default_config and not args.lean and len(all_lamps) > 1:
