@@ -115,6 +115,19 @@ def cpu_baseline(scene, route, waves, photons, flavour=0, budget_s=25.0):
             ref_gpu = {"kernel": "cl/extend.cl render, -O2, correctly rounded divide, no fast-math",
                        "ms_per_launch": round(ms, 3), "mray_s": round(photons / ms / 1e3, 1),
                        "triID_equal_to_oracle": float((rr["triID"] == rays["triID"]).mean())}
+            if orc.refgpu_have_shipped():
+                # the same source with the reference's OWN clBuildProgram options (template/template.cpp:1192):
+                # -cl-fast-relaxed-math -cl-mad-enable -cl-single-precision-constant -- the fairer same-GPU baseline
+                rs = rays.copy()
+                rs["dist"] = np.float32(1e30)
+                rs["triID"] = 0
+                _cnt2, ms2 = orc.refgpu_extend(rs, s.tris, s.nodes, s.triIdx, reps=3, shipped=True)
+                ref_gpu["as_shipped"] = {
+                    "kernel": "cl/extend.cl render with the reference's own flags: -cl-fast-relaxed-math -cl-mad-enable "
+                              "-cl-single-precision-constant (template.cpp:1192)",
+                    "ms_per_launch": round(ms2, 3), "mray_s": round(photons / ms2 / 1e3, 1),
+                    "triID_equal_to_the_strict_build": float((rs["triID"] == rr["triID"]).mean()),
+                    "rays_on_another_triangle_than_the_strict_build": int((rs["triID"] != rr["triID"]).sum())}
     except Exception as e:      # reporting only
         ref_gpu = {"error": str(e)[:200]}
     orc.set_flavour(0)
@@ -129,6 +142,24 @@ def cpu_baseline(scene, route, waves, photons, flavour=0, budget_s=25.0):
                   "semantics), extend uses %d OpenMP threads; extend-only %.2f Mray/s"
                   % (done, waves, photons, cores, done * photons / t_ext / 1e6),
     }, tot, dose
+
+
+def oracle_dose(scene, route, waves, photons, flavour):
+    """Checker for a leg whose arithmetic has no committed CRC: the oracle's dose of the whole step (lamp 0, `waves`
+    launches of `photons`) in `flavour`.  Flavour 2 evaluates v_rcp_f32 through the table read from THIS GPU
+    (oracle/rcp_model.h), which is why its CRC cannot be a committed fixture."""
+    import __graft_entry__ as g
+    orc = g.load_oracle()
+    orc.set_flavour(flavour)
+    try:
+        c = orc.Computation(scene, route["lamps"][:1], photons, route["lightHeight"], route["lightLength"],
+                            route["lightIntensity"], nthreads=host_cores())
+        c.reset()
+        for _ in range(waves):
+            c.iteration()
+        return c.dose()
+    finally:
+        orc.set_flavour(0)
 
 
 _OCL_PROBE = r"""
@@ -191,7 +222,7 @@ def issue_model_utilisation(m, rays, seconds):
     """Utilisation of each unit while `rays` rays are traced in `seconds` of wall time: the kernel's per-ray
     instruction / lookup / byte counts (rocprofv3 PMC passes, deterministic per launch; tests/tools/issue_model.py)
     priced with the issue rates calibrated on this GPU type (tests/tools/valu_calib.hip,
-    profiles/r02_valu_calibration.txt).  Returns (utilisation per unit, [lower, upper] of the VALU figure)."""
+    profiles/r02/r02_valu_calibration.txt).  Returns (utilisation per unit, [lower, upper] of the VALU figure)."""
     k, pr, vc = m["constants"], m["per_ray"], m["valu_issue_cycles"]
     simd_cycles = k["simds"] * k["clock_hz"] * seconds
     cu_cycles = k["cus"] * k["clock_hz"] * seconds
@@ -203,6 +234,86 @@ def issue_model_utilisation(m, rays, seconds):
     }
     scale = rays / m["rays_per_launch"]
     return util, [vc["lower"] * scale / simd_cycles, vc["upper"] * scale / simd_cycles]
+
+
+class Watchdog:
+    """A rank that does not get through `stage` (a rendezvous, a collective init: calls that wait for OTHER ranks) within
+    `seconds` says so and exits non-zero; the parent (spawn_ranks / torch.distributed.run) then stops the others.  The
+    process ends, nothing is re-exec'd."""
+
+    def __init__(self, stage, seconds=None):
+        import threading
+        self.stage = stage
+        self.seconds = float(os.environ.get("UVRT_RENDEZVOUS_TIMEOUT_S", "300")) if seconds is None else seconds
+        self.timer = threading.Timer(self.seconds, self.fire)
+        self.timer.daemon = True
+
+    def fire(self):
+        sys.stderr.write("bench.py: rank %s stuck in '%s' for %.0f s -- exiting 3\n"
+                         % (os.environ.get("RANK", "0"), self.stage, self.seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+def spawn_ranks(n):
+    """Start `n` ranks of this script as CHILD processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, the same command line), relay rank 0's stdout, and return the exit status: 0 only if every rank
+    exited 0.  The caller has not touched the GPU -- nothing is re-exec'd.  A rank that dies takes the others with it
+    (they would wait for it in a collective for ever); a job that outlives UVRT_BENCH_TIMEOUT_S (default 1500) is
+    killed rank by rank -- the exact PIDs started here -- and the status is non-zero, with the ranks still running named."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(sk.getsockname()[1])
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit = float(os.environ.get("UVRT_BENCH_TIMEOUT_S", "1500"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    t0 = time.time()
+    status = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                status = next((c for c in codes if c), 0)
+                break
+            failed = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            late = time.time() - t0 > limit
+            if failed or late:
+                running = [r for r, c in enumerate(codes) if c is None]
+                sys.stderr.write("bench.py --gpus %d: %s; stopping rank(s) %s\n"
+                                 % (n, ("rank(s) %s exited non-zero" % failed) if failed else
+                                    ("no result after %.0f s" % limit), running))
+                status = next((c for c in codes if c), 1) if failed else 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return status
 
 
 def main():
@@ -234,9 +345,11 @@ def main():
     ap.add_argument("--wide", action="store_true",
                     help="opt-in 4-wide BVH walk (include/uvrt.h uvrt_set_wide_bvh): not the reference's visit order; the "
                          "dose check against the oracle still applies (it fails on a scene with order-dependent rays)")
-    ap.add_argument("--flavour", type=int, default=0, choices=[0, 1],
-                    help="arithmetic flavour of IntersectTri (include/uvrt.h uvrt_set_flavour): 0 = canonical strict "
-                         "(SURVEY 8c), 1 = the fused cross/dot ROCm's OpenCL gives the reference's extend.cl on gfx950")
+    ap.add_argument("--flavour", type=int, default=0, choices=[0, 1, 2],
+                    help="arithmetic flavour of extend (include/uvrt.h uvrt_set_flavour): 0 = canonical strict "
+                         "(SURVEY 8c), 1 = the fused cross/dot ROCm's OpenCL gives the reference's extend.cl on gfx950, "
+                         "2 = OPT-IN \"shipped flags\": the arithmetic of extend.cl built with the reference's own "
+                         "-cl-fast-relaxed-math flags on gfx950 (slab test by v_rcp_f32 and a multiply)")
     ap.add_argument("--seed-mode", type=int, default=0, choices=[0, 1],
                     help="SEED semantics of generate.cl (include/uvrt.h uvrt_set_seed_mode): 0 = canonical (SURVEY 8c), "
                          "1 = what the reference's kernel does on gfx950; with --flavour 1 the reference's live kernel chain")
@@ -244,9 +357,18 @@ def main():
                     help="N = 1 rehearsal of a rank's step of the sharded job: a one-rank RCCL communicator, so that every "
                          "computation launches the real all-reduce kernel of the count planes (uvrt_reduce_batch) between its "
                          "tracing and its replay; with --photons 259200 the step is a rank's share of the 8-GPU step")
+    ap.add_argument("--comm", choices=["native", "torch"], default="native",
+                    help="N > 1 (and --self-comm): who all-reduces the count planes -- native = the context's own RCCL "
+                         "communicator (uvrt_reduce_batch), torch = torch.distributed's RCCL all-reduce of the same device "
+                         "planes (the fallback the run takes by itself when the native communicator is unavailable on any rank)")
     ap.add_argument("--high-priority-stream", action="store_true",
                     help="the context's stream (replay, collective) is created with high priority; the launch lanes keep the default")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process has made no GPU call (torch is not even imported yet); it
+        # starts one fresh child per rank, relays rank 0's line and exits with the children's status
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -256,9 +378,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
@@ -271,12 +390,19 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    self_torch = args.self_comm and args.comm == "torch"     # N = 1 rehearsal of the torch-fallback branch
+    if world > 1 or self_torch:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if self_torch:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        with Watchdog("torch.distributed rendezvous (%s)" % ("gloo" if rehearsal else "nccl")):
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     coll_device = "cpu" if rehearsal else device
 
     import __graft_entry__ as g
@@ -336,34 +462,49 @@ def main():
     # ---- the sharded (strong) computation: ray ranges + one collective per batch ---------------------------
     native_comm = False
     comm_note = ""
-    if world > 1 and not rehearsal:
-        # the context's own RCCL communicator (uvrt_comm_init_rank); should it fail on ANY rank, every rank reduces the
-        # planes with torch.distributed's RCCL all-reduce on the device instead (same collective, one more host call)
-        ok, why = 1, ""
-        try:
-            ids = [capi.comm_unique_id() if rank == 0 else None]
-        except Exception as e:          # noqa: BLE001  (reported in the line)
-            ids, ok, why = [None], 0, str(e)
-        dist.broadcast_object_list(ids, src=0)
-        if ok and ids[0] is not None:
+    comm_info = None
+    if world > 1 and not rehearsal and args.comm == "native":
+        # the context's own RCCL communicator (uvrt_comm_init_rank); should it be unavailable on ANY rank, every rank
+        # reduces the planes with torch.distributed's RCCL all-reduce on the device instead (same collective, one more
+        # host call).  ncclCommInitRank is itself a collective, so the ranks first agree on a LOCAL precondition
+        # (librccl opens, its symbols resolve, rank 0 got an id): nobody enters the init unless everybody will.
+        ok, why = capi.comm_available()
+        ids = [None]
+        if ok and rank == 0:
             try:
-                rt.ctx.comm_init_rank(ids[0], rank, world)
-            except Exception as e:      # noqa: BLE001
-                ok, why = 0, str(e)
-        else:
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                ids = [capi.comm_unique_id()]
+            except Exception as e:          # noqa: BLE001  (reported in the line)
+                ok, why = False, str(e)
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        native_comm = bool(int(flag.item()))
-        if not native_comm:
-            if ok:
+        if int(flag.item()):
+            dist.broadcast_object_list(ids, src=0)
+            ok = True
+            try:
+                with Watchdog("uvrt_comm_init_rank (ncclCommInitRank, %d ranks)" % world):
+                    rt.ctx.comm_init_rank(ids[0], rank, world)
+            except Exception as e:      # noqa: BLE001
+                ok, why = False, str(e)
+            flag = torch.tensor([int(ok)], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native_comm = bool(int(flag.item()))
+            if not native_comm and ok:
                 rt.ctx.comm_destroy()
+        if not native_comm:
             comm_note = "native communicator unavailable (%s): torch.distributed RCCL all-reduce of the planes" % (why or "another rank failed")
+    elif world > 1 and not rehearsal:
+        comm_note = "--comm torch: torch.distributed RCCL all-reduce of the planes"
     if args.self_comm:
         if world != 1 or args.mode != "batched":
             raise SystemExit("--self-comm is the N = 1 rehearsal of the batched, sharded step")
-        rt.ctx.comm_init_rank(capi.comm_unique_id(), 0, 1)
-        rt.set_reduce_over_comm(True)
+        if not self_torch:
+            rt.ctx.comm_init_rank(capi.comm_unique_id(), 0, 1)
+            rt.set_reduce_over_comm(True)
+    if native_comm or (args.self_comm and not self_torch):
+        comm_info = rt.ctx.comm_info()
+        if comm_info["rccl_ranks"] != world:
+            raise SystemExit("bench: RCCL says the communicator spans %d ranks, the job has %d" % (comm_info["rccl_ranks"], world))
+    torch_reduce = (world > 1 and not rehearsal and not native_comm) or self_torch
     share = (n_launch + world - 1) // world
     first = min(rank * share, n_launch)
     mine = min(share, n_launch - first)
@@ -371,7 +512,7 @@ def main():
     def step_batched():
         rt.ctx.seed = 0                       # every step is the same computation (fresh-Init SEED)
         rt.ResetDosageMap()
-        if world > 1 and not rehearsal and not native_comm:
+        if torch_reduce:
             # the same step with torch.distributed's RCCL all-reduce of the device planes (the stream is torch's current one)
             ops = np.zeros(args.waves, dtype=capi.REPLAY_OP_DT)
             for k in range(args.waves):
@@ -519,6 +660,33 @@ def main():
                 rt.ctx.set_seed_mode(0)
                 if exp_r is not None and crc_r != exp_r:
                     raise SystemExit("bench: seed-mode-1 / flavour-1 dose CRC %s differs from the oracle's %s" % (crc_r, exp_r))
+            # ---- OPT-IN "shipped flags" arithmetic (uvrt_set_flavour 2): what the reference's own build flags compute on
+            # gfx950 -- one multiply by v_rcp_f32 per slab distance instead of an exact division.  Checked against the
+            # oracle in that flavour (v_rcp_f32 through the table read from this GPU) and, per ray, against the reference
+            # kernel built with those flags (tests/test_gpu_shipped_flags.py)
+            if args.flavour == 0 and args.seed_mode == 0 and not args.wide:
+                orc_s = g.load_oracle()
+                if orc_s.refgpu() is not None:
+                    rt.ctx.set_flavour(2)
+                    el_f = timed(headline, 1, args.steps)
+                    dose_f = rt.read_dosage()
+                    rt.ctx.set_flavour(0)
+                    leg = {"value": round(rays_per_step * args.steps / el_f / 1e6, 2), "ms_per_step": round(el_f / args.steps * 1e3, 4),
+                           "dose_crc32": crc(dose_f), "mode": args.mode,
+                           "note": "--flavour 2: slab distances as (b - o) * v_rcp_f32(d), f = v_rcp_f32(a) -- the arithmetic of "
+                                   "cl/extend.cl under the reference's own -cl-fast-relaxed-math build (template.cpp:1192) on this "
+                                   "GPU; opt-in, the default stays flavour 0"}
+                    if default_config and not args.no_cpu_baseline:
+                        if oscene is None:
+                            oscene = orc_s.Scene(glb)
+                        ref_f = oracle_dose(oscene, orc_s.load_route(route_xml), args.waves, n_launch, 2)
+                        leg["dose_crc32_expected"] = crc(ref_f)
+                        leg["expected_is"] = "the oracle in flavour 2, computed in this run (v_rcp_f32 table read from this GPU)"
+                        rel = np.abs(dose_f.astype(np.float64) - dose_timed) / np.maximum(np.abs(dose_timed.astype(np.float64)), 1e-30)
+                        leg["triangles_beyond_1e-4_of_flavour0"] = int((rel > 1e-4).sum())
+                        if leg["dose_crc32"] != leg["dose_crc32_expected"]:
+                            raise SystemExit("bench: flavour-2 dose CRC %s differs from the oracle's %s" % (leg["dose_crc32"], leg["dose_crc32_expected"]))
+                    other_modes["shipped_flags_flavour"] = leg
             # ---- a lamp position the context has never seen: the hot-record set-up (uvrt_hotset.hip) is inside ------
             if len(all_lamps) > 1 and not args.route:
                 # five positions next to lamp 1 of the route, none of them seen before (and none a lamp of the route, whose own
@@ -656,7 +824,7 @@ def main():
             raise SystemExit("bench: dose CRC %s of the timed region differs from the committed %s" % (crc_timed, expected))
         if census is None and os.path.exists(census_path()) and default_config:
             census = json.load(open(census_path()))["per_launch_avg"]
-        kernel_name = "k_extend6<2,false,true,%s>" % ("true" if args.flavour else "false")
+        kernel_name = "k_extend6<2, false, true, %d>" % args.flavour
         roof = None
         if ext_launches:
             avg_ms = ext_ms / max(ext_launches, 1)
@@ -749,12 +917,19 @@ def main():
                        "launch_pipelining": bool(not args.no_pipeline), "flavour": args.flavour, "seed_mode": args.seed_mode,
                        "wide_bvh": bool(args.wide), "parallelism": par,
                        "self_comm": bool(args.self_comm), "high_priority_stream": bool(args.high_priority_stream)},
+            # who reduced the count planes, and what RCCL itself says the communicator spans (ncclCommCount)
+            "comm": ("native" if (native_comm or (args.self_comm and not self_torch)) else "torch" if torch_reduce else
+                     "REHEARSAL (gloo; ranks share a GPU)" if rehearsal else None),
+            "rccl_ranks": comm_info["rccl_ranks"] if comm_info else (dist.get_world_size() if torch_reduce else None),
+            "reserved_cus": comm_info["reserved_cus"] if comm_info else 0,
+            "ranks_agree": ranks_agree, "comm_note": comm_note or None,
             "roofline": roof, "cpu_baseline": cpu,
             "dose_crc32": crc_timed, "dose_crc32_expected": expected, "dose_crc32_after_all_passes": crc(dose_after),
             "value_is": "steady-state throughput of back-to-back computations (one device sync after the last step)",
         }
         if world == 1:
-            same_semantics = [v["dose_crc32"] for k, v in other_modes.items() if k != "reference_live_chain_semantics"]
+            same_semantics = [v["dose_crc32"] for k, v in other_modes.items()
+                              if k not in ("reference_live_chain_semantics", "shipped_flags_flavour")]
             if crc(dose_after) != crc_timed or any(c != crc_timed for c in same_semantics):
                 raise SystemExit("bench: the passes disagree on the dose (%s / %s / %s)" % (crc_timed, other_modes, crc(dose_after)))
             if single_ms is not None:
@@ -769,12 +944,14 @@ def main():
             out["weak"] = weak
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        with Watchdog("final barrier"):
+            dist.barrier()
         if native_comm:
             rt.ctx.comm_destroy()
-        dist.destroy_process_group()
-    if args.self_comm:
+    if args.self_comm and not self_torch:
         rt.ctx.comm_destroy()
+    if dist.is_initialized():
+        dist.destroy_process_group()
     rt.close()
 
 

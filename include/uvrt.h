@@ -166,10 +166,17 @@ int uvrt_read_batch_counts(uvrt_ctx* ctx, int32_t launch, int32_t* out, int32_t 
  * uvrt_replay_batch.  One process driving several GPUs: uvrt_comm_init_all over one context per device and
  * uvrt_reduce_batch_group.  uvrt_reduce_batch_group without communicators sums contexts that share ONE
  * device (rehearsals and tests of the sharded path on a single-GPU box). */
+/* 1 when librccl opens and every entry point used here resolves, else 0 (text in uvrt_last_error): a LOCAL
+ * precondition.  uvrt_comm_init_rank is itself a collective (ncclCommInitRank): ranks agree on this flag over their
+ * out-of-band channel first, so that a rank without RCCL cannot leave the others waiting inside the init. */
+int uvrt_comm_available(void);
 int uvrt_comm_unique_id(void* id128);
 int uvrt_comm_init_rank(uvrt_ctx* ctx, const void* id128, int32_t rank, int32_t world);
 int uvrt_comm_init_all(uvrt_ctx** ctxs, int32_t n);
 int uvrt_comm_destroy(uvrt_ctx* ctx);
+/* what the context's communicator is: out4 = { world given at init (0: none), rank, ncclCommCount of the native
+ * communicator (what RCCL itself spans; 0: none), compute units the launch lanes leave to the collective } */
+int uvrt_comm_info(uvrt_ctx* ctx, int32_t out4[4]);
 int uvrt_reduce_batch(uvrt_ctx* ctx);
 int uvrt_reduce_batch_group(uvrt_ctx** ctxs, int32_t n);
 
@@ -180,11 +187,21 @@ int uvrt_set_sort_bits(uvrt_ctx* ctx, int32_t bits);
 /* record (dist, triID) per ray in gid order during extend (the reference updates rays in
  * place, extend.cl:90-92); off by default, needed by uvrt_read_rays. */
 int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
-/* arithmetic flavour of IntersectTri's cross()/dot(): 0 (default) = the canonical strict flavour
- * of SURVEY.md 8c (unfused); 1 = "ocl-amd", the fused multiply-add forms that ROCm's OpenCL
- * device library gives the reference's extend.cl on gfx950 -- results then equal that kernel's,
- * run live on the same GPU, bit for bit.  Everything else (slab test, traversal, deposit) is
- * common to both flavours. */
+/* arithmetic flavour of extend (cl/extend.cl:6-38):
+ *   0 (default) = the canonical strict flavour of SURVEY.md 8c: every operator one IEEE rounding in source order,
+ *     correctly rounded divisions -- bit-exact against a CPU restatement unconditionally;
+ *   1 = "ocl-amd": IntersectTri's cross()/dot() in the fused multiply-add forms ROCm's OpenCL device library gives the
+ *     reference's extend.cl on gfx950 (strict build) -- results equal that kernel's, run
+ *     live on the same GPU, bit for bit; slab test, traversal and deposit as flavour 0;
+ *   2 = "shipped flags" (OPT-IN): the arithmetic the reference's OWN clBuildProgram options (-cl-fast-relaxed-math
+ *     -cl-mad-enable -cl-single-precision-constant, template/template.cpp:1192) make of extend.cl on gfx950, read
+ *     off the disassembly of that build: IntersectAABB's t = (b - o) * v_rcp_f32(d) (one multiply by the hardware's
+ *     approximate reciprocal instead of a division, cl/extend.cl:31-35), IntersectTri as flavour 1 with
+ *     f = v_rcp_f32(a) (extend.cl:17).  (dist bits, triID, counts) equal that kernel's bit for bit; against
+ *     flavours 0 / 1 a few rays per million land on a neighbouring triangle (the dose stays within 1e-4).  v_rcp_f32
+ *     is specific to the GPU generation: a CPU restatement reproduces this flavour only with the instruction's table
+ *     read from the device.  Not available with the opt-in 4-wide walk.  Rays whose direction
+ *     has all three components zero or NaN are outside this flavour's parity domain. */
 int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
 /* OPT-IN 4-wide traversal: uvrt_extend walks a one-level collapse of the caller's BVH
  * (a node holds its grandchildren's boxes) -- about half the loop trips per ray, the same box and triangle

@@ -83,6 +83,11 @@ def lib():
         L.orc_floor_height.argtypes = [C.c_void_p, C.c_int32]
         L.orc_set_flavour.restype = None
         L.orc_set_flavour.argtypes = [C.c_int]
+        L.orc_set_rcp_table.restype = None
+        L.orc_set_rcp_table.argtypes = [C.c_void_p]
+        L.orc_have_rcp_table.restype = C.c_int
+        L.orc_rcp_model.restype = C.c_float
+        L.orc_rcp_model.argtypes = [C.c_float]
         L.orc_extend_steps.restype = None
         L.orc_extend_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_extend_visit_hist.restype = None
@@ -215,9 +220,28 @@ def generate_fixed_seed(first, n, lp, lightLength, SEED, saturate=False):
     return rays, int(s0)
 
 
+_RCP_TABLE = None
+
+
 def set_flavour(flavour):
-    """0 = canonical strict arithmetic (default), 1 = "ocl-amd" (uvrt_oracle.h)."""
+    """0 = canonical strict arithmetic (default), 1 = "ocl-amd", 2 = "shipped flags" (uvrt_oracle.h).  Flavour 2
+    evaluates v_rcp_f32 through a table read from the GPU (refgpu_rcp_table): it exists only on a GPU box."""
+    if int(flavour) == 2 and not lib().orc_have_rcp_table():
+        set_rcp_table(refgpu_rcp_table())
     lib().orc_set_flavour(int(flavour))
+
+
+def set_rcp_table(table):
+    """2^23 uint32: bits of v_rcp_f32(1.m) per significand m (kept alive here: the C side keeps the pointer)"""
+    global _RCP_TABLE
+    table = np.ascontiguousarray(table, dtype=np.uint32)
+    assert table.size == 1 << 23
+    _RCP_TABLE = table
+    lib().orc_set_rcp_table(_p(table))
+
+
+def rcp_model(x):
+    return float(lib().orc_rcp_model(float(np.float32(x))))
 
 
 def extend(temp, tris, rays, nodes, triIdx, nthreads=0):
@@ -365,6 +389,10 @@ def refgpu():
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.refgpu_generate.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_float,
                                       C.POINTER(C.c_double)]
+        L.refgpu_extend_shipped.argtypes = L.refgpu_extend.argtypes
+        L.refgpu_generate_shipped.argtypes = L.refgpu_generate.argtypes
+        L.refgpu_rcp_table.argtypes = [C.c_void_p]
+        L.refgpu_rcp_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
         L.refgpu_shade.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
         L.refgpu_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
@@ -376,17 +404,45 @@ def refgpu():
     return _REFGPU
 
 
-def refgpu_extend(rays, tris, nodes, triIdx, reps=1):
+def refgpu_extend(rays, tris, nodes, triIdx, reps=1, shipped=False):
     """extend.cl:render of the reference on the GPU.  rays (RAY_DT, len % 256 == 0) is updated in
-    place; returns (counts, kernel_ms)."""
+    place; returns (counts, kernel_ms).  shipped = the build with the reference's own flags (ref_extend_fast.co)."""
     L = refgpu()
     assert rays.size % 256 == 0
     counts = np.zeros(tris.shape[0], dtype=np.int32)
     ms = C.c_double()
-    if L.refgpu_extend(_p(rays), rays.size, _p(tris), tris.shape[0], _p(nodes), nodes.shape[0], _p(triIdx),
-                       _p(counts), C.byref(ms), int(reps)) != 0:
+    fn = L.refgpu_extend_shipped if shipped else L.refgpu_extend
+    if fn(_p(rays), rays.size, _p(tris), tris.shape[0], _p(nodes), nodes.shape[0], _p(triIdx),
+          _p(counts), C.byref(ms), int(reps)) != 0:
         raise RuntimeError("refgpu_extend: " + L.refgpu_last_error().decode())
     return counts, float(ms.value)
+
+
+def refgpu_have_shipped():
+    L = refgpu()
+    return L is not None and bool(L.refgpu_have_shipped())
+
+
+def refgpu_rcp_table():
+    """bits of v_rcp_f32(1.m) for all 2^23 significands, read from the GPU (oracle/rcp_probe.hip)"""
+    L = refgpu()
+    if L is None:
+        raise RuntimeError("flavour 2 needs the GPU-side probe (oracle/libref_gpu.so) and a gfx950")
+    table = np.empty(1 << 23, dtype=np.uint32)
+    if L.refgpu_rcp_table(_p(table)) != 0:
+        raise RuntimeError("refgpu_rcp_table failed")
+    return table
+
+
+def refgpu_rcp_check(table, cap=64):
+    """oracle/rcp_model.h (built from `table`) against v_rcp_f32 on all 2^32 inputs: (mismatches, first few (x, hw, model))"""
+    L = refgpu()
+    n = C.c_uint64()
+    bad = np.zeros((cap, 3), dtype=np.uint32)
+    table = np.ascontiguousarray(table, dtype=np.uint32)
+    if L.refgpu_rcp_check(_p(table), C.byref(n), _p(bad), cap) != 0:
+        raise RuntimeError("refgpu_rcp_check failed")
+    return int(n.value), bad[:min(cap, int(n.value))]
 
 
 def refgpu_reload():
@@ -395,14 +451,15 @@ def refgpu_reload():
         raise RuntimeError("refgpu_reload: " + refgpu().refgpu_last_error().decode())
 
 
-def refgpu_generate(n, lp, lightLength):
+def refgpu_generate(n, lp, lightLength, shipped=False):
     """generate.cl:render of the reference on the GPU over n work-items (n % 256 == 0), with whatever
-    SEED the loaded module holds.  Returns (rays, kernel_ms)."""
+    SEED the loaded module holds.  Returns (rays, kernel_ms).  shipped = the build with the reference's own flags."""
     L = refgpu()
     assert n % 256 == 0
     rays = np.zeros(n, dtype=RAY_DT)
     ms = C.c_double()
-    if L.refgpu_generate(_p(rays), int(n), _f3(lp), float(np.float32(lightLength)), C.byref(ms)) != 0:
+    fn = L.refgpu_generate_shipped if shipped else L.refgpu_generate
+    if fn(_p(rays), int(n), _f3(lp), float(np.float32(lightLength)), C.byref(ms)) != 0:
         raise RuntimeError("refgpu_generate: " + L.refgpu_last_error().decode())
     return rays, float(ms.value)
 

@@ -30,6 +30,11 @@ std::string g_err;
 hipModule_t g_mod[5];
 hipFunction_t g_generate, g_extend, g_accumulate, g_reset, g_compute_dosage, g_dosage_to_color;
 bool g_loaded = false;
+// the same sources built with the reference's OWN clBuildProgram options (template.cpp:1192; oracle/Makefile
+// CLFLAGS_SHIPPED): ref_generate_fast.co, ref_extend_fast.co -- optional, loaded when present
+hipModule_t g_mod_shipped[2];
+hipFunction_t g_generate_shipped, g_extend_shipped;
+bool g_shipped = false;
 
 int fail(const char* what, hipError_t e)
 {
@@ -61,8 +66,23 @@ int refgpu_load(const char* dir)
     TRY(hipModuleGetFunction(&g_compute_dosage, g_mod[4], "computeDosage"));
     TRY(hipModuleGetFunction(&g_dosage_to_color, g_mod[4], "dosageToColor"));
     g_loaded = true;
+    g_shipped = false;
+    {
+        const std::string pg = std::string(dir) + "/ref_generate_fast.co", pe = std::string(dir) + "/ref_extend_fast.co";
+        FILE* f = fopen(pe.c_str(), "rb");
+        if (f) {
+            fclose(f);
+            TRY(hipModuleLoad(&g_mod_shipped[0], pg.c_str()));
+            TRY(hipModuleLoad(&g_mod_shipped[1], pe.c_str()));
+            TRY(hipModuleGetFunction(&g_generate_shipped, g_mod_shipped[0], "render"));
+            TRY(hipModuleGetFunction(&g_extend_shipped, g_mod_shipped[1], "render"));
+            g_shipped = true;
+        }
+    }
     return 0;
 }
+
+int refgpu_have_shipped(void) { return g_loaded && g_shipped ? 1 : 0; }
 
 // Unload and reload every code object: program-scope variables start from their initialisers again,
 // i.e. SEED = 0 like after RayTracer::Init's `new Kernel("cl/generate.cl", "render")` (raytracer.cpp:17).
@@ -71,6 +91,7 @@ int refgpu_reload(void)
     if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
     TRY(hipDeviceSynchronize());
     for (int i = 0; i < 5; ++i) TRY(hipModuleUnload(g_mod[i]));
+    if (g_shipped) for (int i = 0; i < 2; ++i) TRY(hipModuleUnload(g_mod_shipped[i]));
     g_loaded = false;
     const std::string d = g_dir;
     return refgpu_load(d.c_str());
@@ -95,8 +116,8 @@ static int launch1d(hipFunction_t f, size_t count, void** args)
 
 // extend.cl:render over n rays (n % 256 == 0).  rays32 (host, 32-byte Ray records) is updated in
 // place with dist/triID, counts (host, int[T]) receives tempPhotonMap.  *ms = kernel time.
-int refgpu_extend(void* rays32, int64_t n, const void* tris64, int32_t T, const void* nodes32,
-                  int32_t node_count, const uint32_t* tri_idx, int32_t* counts, double* ms, int reps)
+static int extend_with(hipFunction_t fn, void* rays32, int64_t n, const void* tris64, int32_t T, const void* nodes32,
+                       int32_t node_count, const uint32_t* tri_idx, int32_t* counts, double* ms, int reps)
 {
     if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
     void *d_rays = nullptr, *d_tris = nullptr, *d_nodes = nullptr, *d_idx = nullptr, *d_counts = nullptr;
@@ -119,7 +140,7 @@ int refgpu_extend(void* rays32, int64_t n, const void* tris64, int32_t T, const 
         TRY(hipMemset(d_counts, 0, (size_t)T * 4));
         TRY(hipDeviceSynchronize());
         TRY(hipEventRecord(e0, nullptr));
-        if (launch1d(g_extend, (size_t)n, args)) return -1;
+        if (launch1d(fn, (size_t)n, args)) return -1;
         TRY(hipEventRecord(e1, nullptr));
         TRY(hipEventSynchronize(e1));
         float t = 0;
@@ -134,8 +155,35 @@ int refgpu_extend(void* rays32, int64_t n, const void* tris64, int32_t T, const 
     return 0;
 }
 
+int refgpu_extend(void* rays32, int64_t n, const void* tris64, int32_t T, const void* nodes32,
+                  int32_t node_count, const uint32_t* tri_idx, int32_t* counts, double* ms, int reps)
+{
+    return extend_with(g_extend, rays32, n, tris64, T, nodes32, node_count, tri_idx, counts, ms, reps);
+}
+
+// the same kernel as the reference's own build flags compile it (ref_extend_fast.co)
+int refgpu_extend_shipped(void* rays32, int64_t n, const void* tris64, int32_t T, const void* nodes32,
+                          int32_t node_count, const uint32_t* tri_idx, int32_t* counts, double* ms, int reps)
+{
+    if (!g_shipped) { g_err = "refgpu: ref_extend_fast.co was not built (make -C oracle ref)"; return -1; }
+    return extend_with(g_extend_shipped, rays32, n, tris64, T, nodes32, node_count, tri_idx, counts, ms, reps);
+}
+
+static int generate_with(hipFunction_t fn, void* rays32_out, int64_t n, const float light_pos[3], float light_length, double* ms);
+
 // generate.cl:render over n work-items (n % 256 == 0).  rays32_out may be NULL (timing only).
 int refgpu_generate(void* rays32_out, int64_t n, const float light_pos[3], float light_length, double* ms)
+{
+    return generate_with(g_generate, rays32_out, n, light_pos, light_length, ms);
+}
+
+int refgpu_generate_shipped(void* rays32_out, int64_t n, const float light_pos[3], float light_length, double* ms)
+{
+    if (!g_shipped) { g_err = "refgpu: ref_generate_fast.co was not built (make -C oracle ref)"; return -1; }
+    return generate_with(g_generate_shipped, rays32_out, n, light_pos, light_length, ms);
+}
+
+static int generate_with(hipFunction_t fn, void* rays32_out, int64_t n, const float light_pos[3], float light_length, double* ms)
 {
     if (!g_loaded) { g_err = "refgpu_load first"; return -1; }
     void* d_rays = nullptr;
@@ -146,7 +194,7 @@ int refgpu_generate(void* rays32_out, int64_t n, const float light_pos[3], float
     TRY(hipEventCreate(&e0));
     TRY(hipEventCreate(&e1));
     TRY(hipEventRecord(e0, nullptr));
-    if (launch1d(g_generate, (size_t)n, args)) return -1;
+    if (launch1d(fn, (size_t)n, args)) return -1;
     TRY(hipEventRecord(e1, nullptr));
     TRY(hipEventSynchronize(e1));
     float t = 0;

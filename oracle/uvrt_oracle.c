@@ -7,6 +7,7 @@
  * C operator below is exactly one rounding, in the order the reference source writes it.
  */
 #include "uvrt_oracle.h"
+#include "rcp_model.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -144,12 +145,69 @@ static inline float cl_maxf(float x, float y) { return x < y ? y : x; }
 static int g_flavour = 0;
 void orc_set_flavour(int flavour) { g_flavour = flavour; }
 
+/* flavour 2 ("shipped flags", uvrt_oracle.h): v_rcp_f32 through the table measured on the GPU (rcp_model.h) */
+static const uint32_t* g_rcp_table = NULL;
+void orc_set_rcp_table(const uint32_t* table23) { g_rcp_table = table23; }
+int orc_have_rcp_table(void) { return g_rcp_table != NULL; }
+static inline float hw_rcp(float x)
+{
+    union { float f; uint32_t u; } a, r;
+    a.f = x;
+    r.u = orc_rcp_model_bits(a.u, g_rcp_table);
+    return r.f;
+}
+float orc_rcp_model(float x) { return g_rcp_table ? hw_rcp(x) : NAN; }
+/* v_min_f32 / v_max_f32 in IEEE mode: a NaN operand yields the other one; -0 < +0 */
+static inline float hw_minf(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return signbit(a) ? a : b;
+    return a < b ? a : b;
+}
+static inline float hw_maxf(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return signbit(a) ? b : a;
+    return a < b ? b : a;
+}
+
 /* "ocl-amd" flavour of extend.cl:6-27 (see uvrt_oracle.h): fmaf() is exact also without FMA
  * hardware (glibc software fma) */
 static inline float dot3_fma(float ax, float ay, float az, float bx, float by, float bz)
 {
     return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
+/* extend.cl:6-27 as the reference's own build flags compile it for gfx950 (disassembly of
+ * oracle/_ref/ref_extend_fast.co): the fused cross / dot of the "ocl-amd" flavour, f = v_rcp_f32(a), and the
+ * early returns in the NaN-insensitive forms -cl-fast-relaxed-math licenses: |a| >= 1e-5 continues, 0 <= u && 1 >= u
+ * continues, 0 <= v && 1 >= u + v continues */
+static inline void intersect_tri_shipped(orc_ray* ray, const orc_tri* tri, uint32_t triID)
+{
+    const float e1x = tri->v1x - tri->v0x, e1y = tri->v1y - tri->v0y, e1z = tri->v1z - tri->v0z;
+    const float e2x = tri->v2x - tri->v0x, e2y = tri->v2y - tri->v0y, e2z = tri->v2z - tri->v0z;
+    const float hx = fmaf(ray->diry, e2z, -(ray->dirz * e2y));
+    const float hy = fmaf(ray->dirz, e2x, -(ray->dirx * e2z));
+    const float hz = fmaf(ray->dirx, e2y, -(ray->diry * e2x));
+    const float a = dot3_fma(e1x, e1y, e1z, hx, hy, hz);
+    if (!(fabsf(a) >= 0.00001f)) return;
+    const float f = hw_rcp(a);
+    const float sx = ray->origx - tri->v0x, sy = ray->origy - tri->v0y, sz = ray->origz - tri->v0z;
+    const float u = dot3_fma(sx, sy, sz, hx, hy, hz) * f;
+    if (!(0.0f <= u && 1.0f >= u)) return;
+    const float qx = fmaf(sy, e1z, -(sz * e1y));
+    const float qy = fmaf(sz, e1x, -(sx * e1z));
+    const float qz = fmaf(sx, e1y, -(sy * e1x));
+    const float v = dot3_fma(ray->dirx, ray->diry, ray->dirz, qx, qy, qz) * f;
+    if (!(0.0f <= v && 1.0f >= v + u)) return;
+    const float t = dot3_fma(e2x, e2y, e2z, qx, qy, qz) * f;
+    if (0.0001f < t && t < ray->dist) {
+        ray->dist = t;
+        ray->triID = triID;
+    }
+}
+
 static inline void intersect_tri_ocl(orc_ray* ray, const orc_tri* tri, uint32_t triID)
 {
     const float e1x = tri->v1x - tri->v0x, e1y = tri->v1y - tri->v0y, e1z = tri->v1z - tri->v0z;
@@ -179,6 +237,7 @@ static inline void intersect_tri_ocl(orc_ray* ray, const orc_tri* tri, uint32_t 
 static inline void intersect_tri(orc_ray* ray, const orc_tri* tri, uint32_t triID)
 {
     if (g_flavour == 1) { intersect_tri_ocl(ray, tri, triID); return; }
+    if (g_flavour == 2) { intersect_tri_shipped(ray, tri, triID); return; }
     const float e1x = tri->v1x - tri->v0x, e1y = tri->v1y - tri->v0y, e1z = tri->v1z - tri->v0z;
     const float e2x = tri->v2x - tri->v0x, e2y = tri->v2y - tri->v0y, e2z = tri->v2z - tri->v0z;
     /* h = cross(dir, edge2) */
@@ -204,9 +263,28 @@ static inline void intersect_tri(orc_ray* ray, const orc_tri* tri, uint32_t triI
     }
 }
 
+/* cl/extend.cl:29-38 as the reference's own build flags compile it for gfx950: t = (b - o) * v_rcp_f32(d),
+ * v_min_f32 / v_max_f32 / v_max3_f32 / v_min3_f32 in the source's operand order */
+static inline float intersect_aabb_shipped(const orc_ray* ray, const orc_node* node)
+{
+    const float rx = hw_rcp(ray->dirx), ry = hw_rcp(ray->diry), rz = hw_rcp(ray->dirz);
+    const float tx1 = (node->minx - ray->origx) * rx, tx2 = (node->maxx - ray->origx) * rx;
+    const float ty1 = (node->miny - ray->origy) * ry, ty2 = (node->maxy - ray->origy) * ry;
+    const float tz1 = (node->minz - ray->origz) * rz, tz2 = (node->maxz - ray->origz) * rz;
+    const float tmin = hw_maxf(hw_maxf(hw_minf(tx1, tx2), hw_minf(ty1, ty2)), hw_minf(tz1, tz2));
+    const float tmax = hw_minf(hw_minf(hw_maxf(tx1, tx2), hw_maxf(ty1, ty2)), hw_maxf(tz1, tz2));
+    /* the compiled form of extend.cl:37 (no-NaN licence): a miss is tmax < tmin, or tmax >= tmin with !(0 < tmax) or
+     * tmin >= dist.  It differs from the source's form only when tmin or tmax is NaN, which takes a direction whose
+     * three components are all zero or NaN -- outside the parity domain of this flavour (the product calls that a miss) */
+    int miss = tmax < tmin;
+    if (tmax >= tmin && (!(0.0f < tmax) || tmin >= ray->dist)) miss = 1;
+    return miss ? 1e30f : tmin;
+}
+
 /* cl/extend.cl:29-38 */
 static inline float intersect_aabb(const orc_ray* ray, const orc_node* node)
 {
+    if (g_flavour == 2) return intersect_aabb_shipped(ray, node);
     float tx1 = (node->minx - ray->origx) / ray->dirx, tx2 = (node->maxx - ray->origx) / ray->dirx;
     float tmin = cl_minf(tx1, tx2), tmax = cl_maxf(tx1, tx2);
     float ty1 = (node->miny - ray->origy) / ray->diry, ty2 = (node->maxy - ray->origy) / ray->diry;

@@ -94,8 +94,18 @@ uint32_t orc_generate_fixed_seed(orc_ray* rays, int64_t first, int64_t n, const 
  *   1 "ocl-amd": what the reference's extend.cl becomes when built with ROCm's OpenCL device
  *     library for gfx950 (oracle/_ref): cross(a,b).x = fma(a.y, b.z, -(a.z*b.y)) (and cyclic),
  *     dot(a,b) = fma(a.z, b.z, fma(a.y, b.y, a.x*b.x)); read off the disassembly of
- *     oracle/_ref/ref_extend.co.  Used to compare bit for bit with those kernels on the GPU. */
+ *     oracle/_ref/ref_extend.co.  Used to compare bit for bit with those kernels on the GPU.
+ *   2 "shipped flags": what the reference's extend.cl becomes with the reference's OWN build flags
+ *     (-cl-fast-relaxed-math -cl-mad-enable -cl-single-precision-constant, template/template.cpp:1192) on gfx950,
+ *     read off the disassembly of oracle/_ref/ref_extend_fast.co: IntersectAABB's t = (b - o) * v_rcp_f32(d) with the
+ *     hardware's min / max, IntersectTri as flavour 1 with f = v_rcp_f32(a).  v_rcp_f32 is a hardware approximation:
+ *     the oracle evaluates it through a table read from the GPU (orc_set_rcp_table, rcp_model.h), so this flavour
+ *     exists only where a gfx950 is at hand; without a table orc_extend must not be called in flavour 2. */
 void orc_set_flavour(int flavour);
+/* 2^23 entries: bits of v_rcp_f32(1.m) per significand m (oracle/rcp_probe.hip:refgpu_rcp_table); the pointer is kept */
+void orc_set_rcp_table(const uint32_t* table23);
+int orc_have_rcp_table(void);
+float orc_rcp_model(float x);
 
 /* analysis helper: node visits per ray (rays untouched) */
 void orc_extend_steps(const orc_tri* tris, const orc_ray* rays, int64_t n, const orc_node* nodes,

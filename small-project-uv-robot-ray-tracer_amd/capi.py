@@ -49,6 +49,8 @@ SYMBOLS = [
     ("uvrt_replay_batch", C.c_int, [_vp, _vp, _i32, _i32]),
     ("uvrt_fold_batch", C.c_int, [_vp]),
     ("uvrt_read_batch_counts", C.c_int, [_vp, _i32, _vp, _i32, _i32]),
+    ("uvrt_comm_available", C.c_int, []),
+    ("uvrt_comm_info", C.c_int, [_vp, C.POINTER(_i32)]),
     ("uvrt_comm_unique_id", C.c_int, [_vp]),
     ("uvrt_comm_init_rank", C.c_int, [_vp, _vp, _i32, _i32]),
     ("uvrt_comm_init_all", C.c_int, [C.POINTER(_vp), _i32]),
@@ -132,6 +134,12 @@ def comm_unique_id():
     if rc != 0:
         raise UvrtError("uvrt error %d: %s" % (rc, lib().uvrt_last_error().decode()))
     return buf.raw
+
+
+def comm_available():
+    """(ok, why): librccl opens and resolves -- the local precondition ranks agree on before comm_init_rank"""
+    ok = bool(lib().uvrt_comm_available())
+    return ok, ("" if ok else lib().uvrt_last_error().decode())
 
 
 def _ctx_array(ctxs):
@@ -288,6 +296,11 @@ class Ctx:
     def comm_init_rank(self, id128, rank, world):
         assert len(id128) == 128
         self._ck(self._L.uvrt_comm_init_rank(self._h, C.c_char_p(id128), int(rank), int(world)))
+
+    def comm_info(self):
+        out = (C.c_int32 * 4)()
+        self._ck(self._L.uvrt_comm_info(self._h, out))
+        return {"world": int(out[0]), "rank": int(out[1]), "rccl_ranks": int(out[2]), "reserved_cus": int(out[3])}
 
     def comm_destroy(self):
         self._ck(self._L.uvrt_comm_destroy(self._h))

@@ -292,7 +292,7 @@ int uvrt_set_scene(uvrt_ctx* c, const void* tris64, int32_t T, const void* nodes
         if ((rc = c->max_map.ensure((size_t)T * 8, true, c->stream))) return rc;
         // 16 deposit replicas (two per XCD: a workgroup deposits into replica blockIdx % 16), at most 64 MiB in
         // total.  Fewer than 8 serialise on the hot triangles' counters; more than ~24 push the planes out of L2 and
-        // every wave then waits for its deposits' memory round trips (profiles/r02_experiments.txt: 64 replicas cost
+        // every wave then waits for its deposits' memory round trips (profiles/r02/r02_experiments.txt: 64 replicas cost
         // the batched step 5 %)
         int R = c->replicas_knob > 0 ? c->replicas_knob : 16;
         while (R > 1 && (size_t)R * (size_t)T * 4 > ((size_t)64 << 20)) R >>= 1;
@@ -424,6 +424,7 @@ int uvrt_set_record_perm(uvrt_ctx* c, const uint32_t* perm, int32_t n)
     HIP_TRY(hipMemcpyAsync(c->perm.p, perm, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_perm = true;
+    c->perm_gen = ++c->perm_clock;       // same address, another renumbering: records prepared from the old one are stale
     return UVRT_OK;
 }
 
@@ -571,7 +572,7 @@ int uvrt_set_record_hits(uvrt_ctx* c, int32_t on)
 }
 int uvrt_set_flavour(uvrt_ctx* c, int32_t flavour)
 {
-    if (!c || (flavour != 0 && flavour != 1)) return fail(UVRT_ERR_INVALID, "uvrt_set_flavour: flavour must be 0 or 1");
+    if (!c || flavour < 0 || flavour > 2) return fail(UVRT_ERR_INVALID, "uvrt_set_flavour: flavour must be 0, 1 or 2");
     c->flavour = flavour;
     return UVRT_OK;
 }

@@ -21,7 +21,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     // deposit replicas per plane: the contention on a hot triangle's counter grows with the rays per plane
     // (16 replicas for 2 M rays), and every replica is read and zeroed again by the replay -- a shard of a launch
     // gets by with 8 (one per XCD)
-    // (a fused batch is happiest with 8-12 replicas even at 2 M rays per plane: +0.4 % over 16, profiles/r03_knobs_room.txt;
+    // (a fused batch is happiest with 8-12 replicas even at 2 M rays per plane: +0.4 % over 16, profiles/r03/r03_knobs_room.txt;
     // the per-launch path keeps the context's 16)
     int R = std::min(c->replicas, 12);
     if ((int64_t)R * 131072 > 2 * n) R = std::min(c->replicas, 8);
@@ -42,6 +42,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     for (int g = 0, acc = 0; g < ngroups; ++g) { gfirst[g] = acc; acc += gsize[g]; }
     GenBatchParams gp;
     memset(&gp, 0, sizeof gp);
+    uint32_t seed_after = c->seed;
     {
         int fill[MAX_BATCH] = {};
         uint32_t seed = c->seed;
@@ -53,7 +54,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             seed = uvrt_seed_next_mode(&lamps[3 * k], light_length, seed, c->seed_mode);
             gp.seed_next[ph] = seed;
         }
-        c->seed = seed;
+        seed_after = seed;              // committed with the batch: a failed call leaves the SEED chain where it was
     }
     // The batch goes into the buffer set the previous batch did NOT use: its lanes start at once -- in the drain of
     // the previous batch, while that one is still being folded / reduced / replayed on the context's stream -- and
@@ -71,6 +72,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                             S.folded.bytes < (size_t)count * (size_t)c->T * 4 || (int)c->b_recs.size() < ngroups || !S.free_ev;
     bool recs_stale = false;
     const uint32_t* gperm[MAX_BATCH] = {};
+    uint64_t ggen[MAX_BATCH] = {};
     uvrt_ctx::HotEntry* fresh[MAX_BATCH];               // lamps the context has not seen: their set-ups go in ONE launch
     uint32_t fresh_prev[MAX_BATCH], fresh_next[MAX_BATCH];
     int nfresh = 0;
@@ -89,7 +91,8 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                 is_fresh = true;
             }
         }
-        if (g >= (int)c->b_recs_key.size() || c->b_recs_key[g].perm != gperm[g] || memcmp(&c->b_recs_key[g].ox, &gx[g], 4) != 0 ||
+        ggen[g] = perm_generation(c, gperm[g]);
+        if (g >= (int)c->b_recs_key.size() || c->b_recs_key[g].perm != gperm[g] || c->b_recs_key[g].gen != ggen[g] || memcmp(&c->b_recs_key[g].ox, &gx[g], 4) != 0 ||
             memcmp(&c->b_recs_key[g].oz, &gz[g], 4) != 0 || is_fresh) {
             recs_stale = true;
             if (g < (int)c->b_recs_key.size()) c->b_recs_key[g].valid = false;
@@ -122,9 +125,9 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
         // per-launch records of the lamp columns whose array holds something else
         for (int g = 0; g < ngroups; ++g) {
             uvrt_ctx::RecsKey& key = c->b_recs_key[g];
-            if (key.perm == gperm[g] && key.valid && memcmp(&key.ox, &gx[g], 4) == 0 && memcmp(&key.oz, &gz[g], 4) == 0) continue;
+            if (key.perm == gperm[g] && key.gen == ggen[g] && key.valid && memcmp(&key.ox, &gx[g], 4) == 0 && memcmp(&key.oz, &gz[g], 4) == 0) continue;
             launch_prepare_launch6(c->pairs.as<PairRec>(), c->b_recs[g].p, gx[g], gz[g], c->npairs, gperm[g], c->stream);
-            key.ox = gx[g]; key.oz = gz[g]; key.perm = gperm[g]; key.valid = true;
+            key.ox = gx[g]; key.oz = gz[g]; key.perm = gperm[g]; key.gen = ggen[g]; key.valid = true;
         }
         HIP_TRY(hipGetLastError());
         if (int rcf = mark_fence(c)) return rcf;         // the lanes' next work waits for the records
@@ -135,7 +138,11 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
     // microseconds), and the next chunk's generate and first waves run in the drain of the previous one.
     bool lane_waited[uvrt_ctx::MAXL] = {};
     const int per_chunk = (int)std::max<size_t>(1, c->batch_chunk_bytes / ((size_t)n_pad * 16));
-    const int lane_before = c->lane;
+    // every error return below leaves the launch-lane rotation as it found it
+    struct LaneGuard {
+        uvrt_ctx* c; int lane; uint64_t chunks; bool armed;
+        ~LaneGuard() { if (armed) { c->lane = lane; c->b_chunks = chunks; } }
+    } guard{c, c->lane, c->b_chunks, true};
     int chunk_index = 0;
     for (int g = 0; g < ngroups; ++g) {
         for (int k0 = 0; k0 < gsize[g]; k0 += per_chunk, ++chunk_index) {
@@ -168,7 +175,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             if (!(c->probe_skip_generate > 0 && c->probe_batches >= c->probe_skip_generate))
 #endif
             launch_generate_batch(gq, ls);
-            if (int rcl = lane_stream(c, &ls)) { c->lane = lane_before; return rcl; }      // extend: after the fence
+            if (int rcl = lane_stream(c, &ls)) return rcl;      // extend: after the fence
             ExtendParams p;
             memset(&p, 0, sizeof p);
             p.scene.pairs = c->pairs.as<PairRec>();
@@ -217,7 +224,6 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
                 HIP_TRY(hipEventRecord(e0, ls));
             }
             if (!launch_extend6(p, variant_code6(c->variant), variant_per_cu(c->variant, c->pipeline ? 7 : 8), ls)) {
-                c->lane = lane_before;
                 return fail(UVRT_ERR_INVALID, "uvrt_trace_batch: variant %d needs a larger overflow-stack buffer", c->variant);
             }
             HIP_TRY(hipGetLastError());
@@ -227,6 +233,8 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
 #ifdef UVRT_DEV_VARIANTS
     ++c->probe_batches;
 #endif
+    guard.armed = false;
+    c->seed = seed_after;
     c->lane = 0;
     c->cur_pipelined = false;
     c->last_n = -1;                      // the per-launch generate/extend pairing starts afresh

@@ -17,6 +17,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -40,6 +41,7 @@ int rccl_load()
     UVRT_SYM(CommInitRank, ncclCommInitRank);
     UVRT_SYM(CommInitAll, ncclCommInitAll);
     UVRT_SYM(CommDestroy, ncclCommDestroy);
+    UVRT_SYM(CommCount, ncclCommCount);
     UVRT_SYM(AllReduce, ncclAllReduce);
     UVRT_SYM(GroupStart, ncclGroupStart);
     UVRT_SYM(GroupEnd, ncclGroupEnd);
@@ -59,7 +61,7 @@ namespace uvrt_impl {
 // batch k + 1 to end instead of running beside it.  So while a communicator is set, the launch lanes' streams are created
 // with a CU mask (hipExtStreamCreateWithCUMask) that leaves `reserve` CUs to the context's stream, where the fold, the
 // collective and the replay run.  On the MI355X mask bit b is XCC b % 8 (tests/tools/cumask_probe.hip,
-// profiles/r03_cumask_probe.txt): clearing the LAST eight bits takes one CU from every XCD, so the round-robin deal of
+// profiles/r03/r03_cumask_probe.txt): clearing the LAST eight bits takes one CU from every XCD, so the round-robin deal of
 // workgroups to XCDs stays balanced.
 int set_lane_cu_mask(uvrt_ctx* c, int reserve)
 {
@@ -72,12 +74,22 @@ int set_lane_cu_mask(uvrt_ctx* c, int reserve)
     const uint32_t words = (uint32_t)((c->num_cus + 31) / 32);
     std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
     for (int k = 0; k < reserve; ++k) { const int bit = c->num_cus - 1 - k; mask[bit / 32] &= ~(1u << (bit % 32)); }
+    // every new stream is created before any lane is touched: a failure midway leaves the lanes as they were.
+    // hipExtStreamCreateWithCUMask takes no flags: masked lanes are BLOCKING streams, i.e. they synchronise implicitly with
+    // the legacy null stream.  The library itself never uses the null stream; a host application that does (synchronous
+    // hipMemcpy, default-stream kernels) serialises with the tracing lanes while a communicator is set.
+    hipStream_t fresh[uvrt_ctx::MAXL] = {};
     for (int l = 1; l < uvrt_ctx::MAXL; ++l) {
-        hipStream_t fresh = nullptr;
-        if (reserve > 0) HIP_TRY(hipExtStreamCreateWithCUMask(&fresh, words, mask.data()));
-        else HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
-        if (c->side[l]) { HIP_TRY(hipStreamSynchronize(c->side[l])); HIP_TRY(hipStreamDestroy(c->side[l])); }
-        c->side[l] = fresh;
+        hipError_t e = reserve > 0 ? hipExtStreamCreateWithCUMask(&fresh[l], words, mask.data())
+                                   : hipStreamCreateWithFlags(&fresh[l], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (int k = 1; k < l; ++k) (void)hipStreamDestroy(fresh[k]);
+            return fail(UVRT_ERR_HIP, "uvrt_comm: cannot create launch-lane stream %d (%s); the lanes keep their streams", l, hipGetErrorString(e));
+        }
+    }
+    for (int l = 1; l < uvrt_ctx::MAXL; ++l) {
+        if (c->side[l]) { (void)hipStreamSynchronize(c->side[l]); (void)hipStreamDestroy(c->side[l]); }
+        c->side[l] = fresh[l];
         c->side_used[l] = false;
         c->side_seen_fence[l] = 0;            // the new stream has seen no fence: it waits for the current ones at first use
         c->side_seen_mapfence[l] = 0;
@@ -105,6 +117,26 @@ int uvrt_comm_unique_id(void* id128)
     if (int rc = rccl_load()) return rc;
     static_assert(sizeof(ncclUniqueId) == 128, "the ABI hands the id over as 128 bytes");
     RCCL_TRY(g_rccl.GetUniqueId((ncclUniqueId*)id128));
+    return UVRT_OK;
+}
+
+int uvrt_comm_available(void)
+{
+    return rccl_load() == UVRT_OK ? 1 : 0;
+}
+
+int uvrt_comm_info(uvrt_ctx* c, int32_t out4[4])
+{
+    if (!c || !out4) return fail(UVRT_ERR_INVALID, "uvrt_comm_info: null pointer");
+    out4[0] = c->comm ? c->comm_world : 0;
+    out4[1] = c->comm ? c->comm_rank : 0;
+    out4[2] = 0;
+    out4[3] = c->lanes_masked_cus;
+    if (c->comm) {
+        int n = 0;
+        RCCL_TRY(g_rccl.CommCount((ncclComm_t)c->comm, &n));      // what RCCL itself says the communicator spans
+        out4[2] = n;
+    }
     return UVRT_OK;
 }
 

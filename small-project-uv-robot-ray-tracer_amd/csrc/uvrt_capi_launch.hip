@@ -65,6 +65,7 @@ int hot_lookup(uvrt_ctx* c, const float lamp[3], hipStream_t s, const uint32_t**
     }
     memcpy(e->lamp, lamp, 12);
     e->stamp = c->hot_clock;
+    e->gen = ++c->perm_clock;            // records prepared from the entry's previous renumbering are stale (uvrt_trace_batch's keys)
     *fresh = e;
     return UVRT_OK;
 }
@@ -299,6 +300,8 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         ++c->ev_used;
         HIP_TRY(hipEventRecord(e0, ls));
     }
+    if (c->wide && c->nquads > 0 && c->flavour == 2)
+        return fail(UVRT_ERR_INVALID, "uvrt_extend: the opt-in 4-wide walk has no \"shipped flags\" arithmetic (uvrt_set_flavour 2)");
     if (c->wide && c->nquads > 0) {
         // the opt-in 4-wide walk: its per-launch records are (re)made here when the lane's are for another lamp
         DevBuf& r4 = c->recs4[c->lane];
@@ -330,7 +333,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     // default grid: 8 workgroups per CU on one stream (20 KB of LDS each: eight fit a CU); 7 when launches are
     // pipelined over several streams -- the free slot per CU lets the first workgroups of the next launch and the
     // small kernels around it (generate, accumulate, replay) run at once instead of queueing behind persistent waves
-    // (profiles/r02_experiments.txt); with four launch lanes 4 per CU
+    // (profiles/r02/r02_experiments.txt); with four launch lanes 4 per CU
     const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : c->cur_pipelined ? 7 : 8;
     if (!launch_extend6(p, variant_code6(c->variant), variant_per_cu(c->variant, per_cu_default), ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);

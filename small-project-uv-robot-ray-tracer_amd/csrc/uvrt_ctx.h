@@ -65,6 +65,8 @@ struct uvrt_ctx {
     int32_t T = 0;
     DevBuf pairs, recs, perm, ltris, leaf_count, area;
     bool have_perm = false;      // the caller's own record renumbering (uvrt_set_record_perm)
+    uint64_t perm_clock = 0;     // stamps every renumbering written into `perm` or a hot entry
+    uint64_t perm_gen = 0;       // stamp of what `perm` holds
     int32_t npairs = 0;
     uint32_t root_ref = uvrt::REF_DONE;
     uint32_t top_pairs = 0;      // inner nodes of the first 7 tree levels (breadth-first prefix of `pairs`)
@@ -96,7 +98,7 @@ struct uvrt_ctx {
     static constexpr int MAXL = 4;    // lane 0 = the context's stream and the buffers above
     bool pipeline = true;             // uvrt_set_pipeline
     int nlanes = 2;                   // developer knob UVRT_LANES (1..MAXL): 3 gain ~1 %, 4 (with 4 workgroups
-                                      // per CU) win only for long launch sequences (profiles/r01_v6_experiments.txt)
+                                      // per CU) win only for long launch sequences (profiles/r01/r01_v6_experiments.txt)
     bool ext_touch = false;           // a count-buffer pointer was handed out since the last fence
     bool ext_touch_maps = false;      // a map / dose / colour pointer was handed out since the last map fence
     bool counts_dirty[MAXL] = {};     // the lane's count buffer holds deposits that were not accumulated
@@ -129,7 +131,7 @@ struct uvrt_ctx {
     // costs no allocation); the visit counters and the hot list are scratch of the three set-up kernels, one set per
     // launch lane (the kernels of one lamp run back to back on one stream and leave the counters zeroed).
     static constexpr int HOT_SLAB = 16, HOT_MAX = 64;
-    struct HotEntry { float lamp[3]; uint32_t* perm; uint64_t stamp; hipEvent_t ready; };
+    struct HotEntry { float lamp[3]; uint32_t* perm; uint64_t stamp; hipEvent_t ready; uint64_t gen; };
     std::vector<HotEntry> hot;
     std::vector<DevBuf> hot_slabs;        // [ceil(entries / HOT_SLAB)]: HOT_SLAB x npairs uint32 each
     DevBuf hot_hist[MAXL], hot_list[MAXL];
@@ -151,7 +153,9 @@ struct uvrt_ctx {
     int batch_lanes = 2;                  // side lanes the chunks of a batch alternate over (developer knob UVRT_BATCH_LANES: 1..3)
     int32_t b_repl = 16;                  // deposit replicas per plane of the traced batch
     std::vector<DevBuf> b_recs;           // [group]
-    struct RecsKey { float ox = 0, oz = 0; const uint32_t* perm = nullptr; bool valid = false; };
+    // `gen` tells two renumberings apart that live at ONE address: the caller's buffer after another
+    // uvrt_set_record_perm, a hot entry recycled for another lamp (perm_clock stamps every (re)written renumbering)
+    struct RecsKey { float ox = 0, oz = 0; const uint32_t* perm = nullptr; uint64_t gen = 0; bool valid = false; };
     std::vector<RecsKey> b_recs_key;      // what b_recs[g] holds
     int32_t b_count = 0;                  // launches of the batch that has not been replayed (0: none)
     int64_t b_n = 0, b_npad = 0;
@@ -318,7 +322,7 @@ inline int auto_sort_bits(int64_t n)
 
 inline bool variant_is_knob(int v) { return v >= 400 && v < 1300; }
 // idle lanes that trigger a refill.  Default 8; 24 for scenes of a million records and more, where a trip is a miss to the
-// fabric whatever its lanes do and fewer, fuller refills are worth 2-3 % (profiles/r03_soup_knobs.txt; the room is flat
+// fabric whatever its lanes do and fewer, fuller refills are worth 2-3 % (profiles/r03/r03_soup_knobs.txt; the room is flat
 // between 8 and 16 and loses at 24)
 inline int variant_refill_min(int v, size_t records)
 {
@@ -342,6 +346,14 @@ int launch_perm(uvrt_ctx* c, const float lamp[3], float light_length, uint32_t s
 int hot_lookup(uvrt_ctx* c, const float lamp[3], hipStream_t s, const uint32_t** out, uvrt_ctx::HotEntry** fresh);
 int hot_build(uvrt_ctx* c, uvrt_ctx::HotEntry* const* entries, const uint32_t* seed_prev, const uint32_t* seed_next, int count,
               float light_length, hipStream_t s, int lane);
+// stamp of the renumbering at `perm` (0: none): what a key of prepared records remembers beside the address
+inline uint64_t perm_generation(const uvrt_ctx* c, const uint32_t* perm)
+{
+    if (!perm) return 0;
+    if (perm == c->perm.as<uint32_t>()) return c->perm_gen;
+    for (const auto& h : c->hot) if (h.perm == perm) return h.gen;
+    return 0;
+}
 // drops every cached renumbering (a new scene); with `slab`, the first slab of the new scene is allocated at once
 int hot_reset(uvrt_ctx* c, bool slab);
 // (re)creates the side lanes' streams with `reserve` CUs masked out, one per XCD and mask word of 8 (0: plain streams)

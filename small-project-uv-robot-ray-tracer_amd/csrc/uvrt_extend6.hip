@@ -9,7 +9,7 @@
 //  * slab distances t = (b - o) / d as PACKED f32, two quotients per instruction:
 //        q0 = a * y;  r = fma(-d, q0, a);  q = fma(r, y, q0)      with y = RN32(1/d)
 //    equals RN32(a / d) for all normal operands -- proven by exhaustion over all 2^46 significand
-//    pairs on the GPU (tests/tools/div3_exhaustive.hip, profiles/r01_div3_exhaustive.log);
+//    pairs on the GPU (tests/tools/div3_exhaustive.hip, profiles/r01/r01_div3_exhaustive.log);
 //  * f = 1 / a of the triangle test (extend.cl:17) as v_rcp_f32 + one Newton step, which is the
 //    correctly rounded reciprocal for every binary32 in [2^-64, 2^64) (tests/tools/rcp_exhaustive.hip);
 //  * the x / z numerators a = b - o use the lamp's launch-uniform coordinates: k_prepare_launch6
@@ -30,7 +30,7 @@ namespace uvrt {
 
 // `exact` is wave-uniform: the record fetch and the descend / push / pop logic are common, only the
 // arithmetic of the box and triangle tests differs.
-template <bool TOP, bool OCL>
+template <bool TOP, int FL>
 __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t stack_base,
                                       const float4* s_top, uint32_t top_pairs, bool leaf_trip, bool exact,
                                       unsigned long long m_act /* lanes holding a ray */)
@@ -86,7 +86,10 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
     if (is_inner) {
         float d0, d1;
         bool h0, h1;
-        if (exact) {
+        if (FL == 2) {        // "shipped flags": t = (b - o) * v_rcp_f32(d) for every lane (there is no other form of it)
+            h0 = box_shipped(w0.x, w0.y, w2.x - L.po.x, w2.y - L.po.x, w0.z, w0.w, L.px.y, L.py.y, L.pz.y, L.po.y, d0);
+            h1 = box_shipped(w1.x, w1.y, w2.z - L.po.x, w2.w - L.po.x, w1.z, w1.w, L.px.y, L.py.y, L.pz.y, L.po.y, d1);
+        } else if (exact) {
             h0 = box_exact(w0.x, w0.y, w2.x - L.po.x, w2.y - L.po.x, w0.z, w0.w, L.px.x, L.py.x, L.pz.x, L.po.y, d0);
             h1 = box_exact(w1.x, w1.y, w2.z - L.po.x, w2.w - L.po.x, w1.z, w1.w, L.px.x, L.py.x, L.pz.x, L.po.y, d1);
         } else {
@@ -120,12 +123,12 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         const uint32_t first = idx - (uint32_t)p.npairs;
         if (count == 15u) count = p.scene.leaf_count[first];
         float dist = L.po.y;
-        tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+        tri6<FL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
              make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
              make_float4(w2.x, w2.y, w2.z, w2.w), exact);
         for (uint32_t i = 1; i < count; ++i) {
             const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
-            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
+            tri6<FL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
         }
         L.po.y = dist;
     }
@@ -140,7 +143,7 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
 // The same step for the common case -- no lane needs the IEEE-division form, no lane's stack has left LDS -- with
 // the control flow written as lane masks instead of divergent branches.  Scalar issue is the dearest resource of
 // this kernel (one instruction per cycle per CU, shared by 32 waves: 32 extra scalar instructions per trip cost
-// 17 % of the launch, profiles/r02_experiments.txt), and hipcc spends ~70 of them per trip on exec bookkeeping
+// 17 % of the launch, profiles/r02/r02_experiments.txt), and hipcc spends ~70 of them per trip on exec bookkeeping
 // for `if (inner) {...} if (both hit) {push} if (none hit) {pop}`.  Here the caller hands over the lane masks of
 // the trip (one vector comparison each), the box arithmetic runs for ALL lanes (a vector instruction costs the
 // same whatever its exec mask; lanes that do not stand at an inner node compute on stale registers and are
@@ -148,7 +151,7 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
 // exec-masked instructions of one asm block.
 //   m_in: lanes at an inner node, m_leaf: lanes that visit their leaf in this trip, m_top: lanes whose record is
 //   in the LDS cache, full: the exec mask of the loop (all 64 lanes)
-template <bool TOP, bool OCL>
+template <bool TOP, int FL>
 __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t stack_base, uint32_t top_base,
                                       unsigned long long m_in, unsigned long long m_leaf, unsigned long long m_top,
                                       unsigned long long full
@@ -198,12 +201,12 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
             const uint32_t first = idx - (uint32_t)p.npairs;
             if (count == 15u) count = p.scene.leaf_count[first];
             float dist = L.po.y;
-            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
+            tri6<FL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID,
                       make_float4(w0.x, w0.y, w0.z, w0.w), make_float4(w1.x, w1.y, w1.z, w1.w),
                       make_float4(w2.x, w2.y, w2.z, w2.w), false);
             for (uint32_t i = 1; i < count; ++i) {
                 const float4* lt = (const float4*)p.recs + ((size_t)idx + i) * 4;
-                tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], false);
+                tri6<FL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], false);
             }
             L.po.y = dist;
         }
@@ -213,8 +216,13 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         v2f x0 = __builtin_shufflevector(w0, w0, 0, 1), z0 = __builtin_shufflevector(w0, w0, 2, 3);
         v2f x1 = __builtin_shufflevector(w1, w1, 0, 1), z1 = __builtin_shufflevector(w1, w1, 2, 3);
         v2f y0 = __builtin_shufflevector(w2, w2, 0, 1), y1 = __builtin_shufflevector(w2, w2, 2, 3);
-        slabs6(x0, y0, z0, L.px, L.py, L.pz, L.po);
-        slabs6(x1, y1, z1, L.px, L.py, L.pz, L.po);
+        if (FL == 2) {
+            slabs6s(x0, y0, z0, L.px, L.py, L.pz, L.po);
+            slabs6s(x1, y1, z1, L.px, L.py, L.pz, L.po);
+        } else {
+            slabs6(x0, y0, z0, L.px, L.py, L.pz, L.po);
+            slabs6(x1, y1, z1, L.px, L.py, L.pz, L.po);
+        }
         float n0, f0, n1, f1;
         box2_fast(x0, y0, z0, x1, y1, z1, n0, f0, n1, f1);
         // extend.cl:36-38,56-76: hit = tmax >= tmin && tmin < dist && tmax > 0 per child; child 1 first iff it is hit
@@ -275,7 +283,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
 //   m0 = inner lanes; m1 = lanes at a leaf, later "child 1 hit"; m2 = lanes with a cached record, later "child 0
 //   hit" (and the v_cmpx results of the triangle test); m3 = lanes visiting their leaf; m4 = scratch masks;
 //   %[code] = scratch (lane count, leaf-trip flag) until it carries the exit code
-// Tried and measured in round 3 (profiles/r03_experiments.txt), both bit-exact, neither kept:
+// Tried and measured in round 3 (profiles/r03/r03_experiments.txt), both bit-exact, neither kept:
 //  * an adaptive leaf rule (leaf trip when >= K lanes stand at a leaf or P trips after the last leaf visit; git cc58a8b):
 //    no (P, K) beat the fixed alternation, and its seven extra scalar instructions per trip cost 0.8 %;
 //  * a one-dword load past L1 (sc1) of a pushed child's record at the push -- a pushed node IS visited later,
@@ -283,9 +291,9 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
 //    6 M-triangle soup beyond every cache.
 //  * run-ahead of the lanes at cached records while the trip's global loads are in flight (their own copies of the record
 //    window under exec = those lanes, repeated while they keep landing on cached records): -4 % on a 6 M-triangle soup, -25 % on
-//    a 1 M one, -63 % on the room (profiles/r03_run_ahead.patch): with 28 waves per CU one wave's wait is the others' issue time.
+//    a 1 M one, -63 % on the room (profiles/r03/r03_run_ahead.patch): with 28 waves per CU one wave's wait is the others' issue time.
 // Arithmetic: slabs / boxes / hit tests are step7's (slabs6, box2_fast, the v_cmpx tail); the triangle test is
-// tri6<OCL> instruction for instruction (extend.cl:6-27), early returns as v_cmpx narrowing of exec.
+// tri6<FL> instruction for instruction (extend.cl:6-27), early returns as v_cmpx narrowing of exec.
 // A kernel with this stream must not spill: scratch use costs the launch pipelining 14 % (measured); the general
 // step is ordered (inner block before leaf block) so that hipcc's allocation fits in the 64 registers.
 #define R7_CROSS_STRICT(dst, ay, bz, az, by) \
@@ -298,32 +306,42 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
     "v_mul_f32 v59, " az ", " bz "\n\t" "v_add_f32 " dst ", v58, v59\n\t"
 #define R7_DOT_OCL(dst, ax, ay, az, bx, by, bz) \
     "v_mul_f32 v58, " ax ", " bx "\n\t" "v_fma_f32 v58, " ay ", " by ", v58\n\t" "v_fma_f32 " dst ", " az ", " bz ", v58\n\t"
-#define R7_TRI(CROSS, DOT)                                                                                          \
+// NEWTON: the refinement of f (flavours 0 / 1: f = RN(1 / a)) or nothing (flavour 2: f = v_rcp_f32(a));
+// the early returns (v_cmpx narrows exec to the lanes that go on): flavours 0 / 1 negate the source's return conditions
+// (a NaN goes on, as in extend.cl built strictly), flavour 2 tests the continue conditions the no-NaN licence of the
+// reference's own build flags makes of them (ref_extend_fast.co: |a| >= 1e-5, 0 <= u, 1 >= u, 0 <= v, 1 >= v + u)
+#define R7_NEWTON_EXACT \
+    "v_fma_f32 v57, -v55, v60, 1.0\n\t"                                     /* f = RN(1 / a): rcp + one Newton step */ \
+    "v_fma_f32 v60, v57, v60, v60\n\t"
+#define R7_NEWTON_NONE
+#define R7_GO_A_STRICT "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v58\n\t"         /* if (fabs(a) < 1e-5f) return */
+#define R7_GO_A_SHIPPED "v_cmpx_le_f32_e32 vcc, 0x3727c5ac, v58\n\t"
+#define R7_GO_01_STRICT(x, pre, y) \
+    "v_cmpx_nlt_f32_e64 %[m2], " x ", 0\n\t" pre "v_cmpx_ngt_f32_e64 %[m2], " y ", 1.0\n\t"
+#define R7_GO_01_SHIPPED(x, pre, y) \
+    "v_cmpx_ge_f32_e64 %[m2], " x ", 0\n\t" pre "v_cmpx_le_f32_e64 %[m2], " y ", 1.0\n\t"
+#define R7_TRI(CROSS, DOT, NEWTON, GO_A, GO_01)                                                                     \
     /* h = cross(dir, e2) -> v52 v53 v54 */                                                                         \
     CROSS("v52", "%[dy]", "v50", "%[dz]", "v49")                                                                    \
     CROSS("v53", "%[dz]", "v48", "%[dx]", "v50")                                                                    \
     CROSS("v54", "%[dx]", "v49", "%[dy]", "v48")                                                                    \
     DOT("v55", "v44", "v45", "v46", "v52", "v53", "v54")                    /* a = dot(e1, h) */                    \
     "v_and_b32 v58, 0x7fffffff, v55\n\t"                                                                                 \
-    "v_cmpx_ngt_f32_e32 vcc, 0x3727c5ac, v58\n\t"                            /* if (fabs(a) < 1e-5f) return */       \
+    GO_A                                                                                                            \
     "v_rcp_f32 v60, v55\n\t"                                                                                        \
     "v_sub_f32 v61, %[ox], v40\n\t"                                         /* s = orig - v0 */                     \
     "v_sub_f32 v62, %[oy], v41\n\t"                                                                                 \
     "v_sub_f32 v63, %[oz], v42\n\t"                                                                                 \
-    "v_fma_f32 v57, -v55, v60, 1.0\n\t"                                     /* f = RN(1 / a): rcp + one Newton step */ \
-    "v_fma_f32 v60, v57, v60, v60\n\t"                                                                              \
+    NEWTON                                                                                                          \
     DOT("v51", "v61", "v62", "v63", "v52", "v53", "v54")                                                            \
     "v_mul_f32 v51, v60, v51\n\t"                                           /* u = f * dot(s, h) */                 \
-    "v_cmpx_nlt_f32_e64 %[m2], v51, 0\n\t"                               /* if (u < 0 || u > 1) return */        \
-    "v_cmpx_ngt_f32_e64 %[m2], v51, 1.0\n\t"                                                                     \
+    GO_01("v51", "", "v51")                                                 /* if (u < 0 || u > 1) return */        \
     CROSS("v52", "v62", "v46", "v63", "v45")                                /* q = cross(s, e1) */                  \
     CROSS("v53", "v63", "v44", "v61", "v46")                                                                        \
     CROSS("v54", "v61", "v45", "v62", "v44")                                                                        \
     DOT("v47", "%[dx]", "%[dy]", "%[dz]", "v52", "v53", "v54")                                                      \
     "v_mul_f32 v47, v60, v47\n\t"                                           /* v = f * dot(dir, q) */               \
-    "v_cmpx_nlt_f32_e64 %[m2], v47, 0\n\t"                               /* if (v < 0 || u + v > 1) return */    \
-    "v_add_f32 v55, v51, v47\n\t"                                                                                   \
-    "v_cmpx_ngt_f32_e64 %[m2], v55, 1.0\n\t"                                                                     \
+    GO_01("v47", "v_add_f32 v55, v51, v47\n\t", "v55")                       /* if (v < 0 || u + v > 1) return */    \
     DOT("v55", "v48", "v49", "v50", "v52", "v53", "v54")                                                            \
     "v_mul_f32 v55, v60, v55\n\t"                                           /* t = f * dot(e2, q) */                \
     "v_cmpx_lt_f32_e32 vcc, 0x38d1b717, v55\n\t"                             /* if (t > 1e-4f && t < dist) */        \
@@ -332,7 +350,40 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
     "v_mov_b32 %[tri], v43\n\t"
 
 #define R7_CLOBBERS "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
-#define R7_BODY(TRI) \
+// the twelve slab distances of a node pair (extend.cl:31-35), x / z numerators already b - o:
+//   exact (flavours 0 / 1): t = RN((b - o) / d) as q0 = a * y; r = fma(-d, q0, a); q = fma(r, y, q0), y = RN(1 / d) -- 2 + 18 packed ops
+//   shipped (flavour 2):    t = (b - o) * v_rcp_f32(d), what the reference's own build flags compile -- 2 + 6 packed ops
+#define R7_SLABS_EXACT \
+        "v_pk_add_f32 v[48:49], v[48:49], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 v[58:59], v[40:41], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[60:61], v[42:43], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[62:63], v[48:49], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_fma_f32 v[40:41], %[px], v[58:59], v[40:41] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[42:43], %[pz], v[60:61], v[42:43] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[48:49], %[py], v[62:63], v[48:49] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[40:41], v[40:41], %[px], v[58:59] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[42:43], v[42:43], %[pz], v[60:61] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[48:49], v[48:49], %[py], v[62:63] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_add_f32 v[50:51], v[50:51], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 v[58:59], v[44:45], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[60:61], v[46:47], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[62:63], v[50:51], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_fma_f32 v[44:45], %[px], v[58:59], v[44:45] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[46:47], %[pz], v[60:61], v[46:47] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[50:51], %[py], v[62:63], v[50:51] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[44:45], v[44:45], %[px], v[58:59] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[46:47], v[46:47], %[pz], v[60:61] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        "v_pk_fma_f32 v[50:51], v[50:51], %[py], v[62:63] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define R7_SLABS_SHIPPED \
+        "v_pk_add_f32 v[48:49], v[48:49], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+        "v_pk_add_f32 v[50:51], v[50:51], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 v[40:41], v[40:41], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[42:43], v[42:43], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[44:45], v[44:45], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[46:47], v[46:47], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[48:49], v[48:49], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+        "v_pk_mul_f32 v[50:51], v[50:51], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+#define R7_BODY(TRI, SLABS) \
         "1:\n\t" \
         "v_cmp_lt_i32_e64 %[m0], -1, %[cur]\n\t" \
         "v_cmp_gt_i32_e64 %[m1], -1, %[cur]\n\t" \
@@ -385,26 +436,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "4:\n\t" \
         "s_cmp_eq_u64 %[m0], 0\n\t" \
         "s_cbranch_scc1 5f\n\t" \
-        "v_pk_add_f32 v[48:49], v[48:49], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
-        "v_pk_mul_f32 v[58:59], v[40:41], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
-        "v_pk_mul_f32 v[60:61], v[42:43], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
-        "v_pk_mul_f32 v[62:63], v[48:49], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
-        "v_pk_fma_f32 v[40:41], %[px], v[58:59], v[40:41] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[42:43], %[pz], v[60:61], v[42:43] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[48:49], %[py], v[62:63], v[48:49] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[40:41], v[40:41], %[px], v[58:59] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
-        "v_pk_fma_f32 v[42:43], v[42:43], %[pz], v[60:61] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
-        "v_pk_fma_f32 v[48:49], v[48:49], %[py], v[62:63] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
-        "v_pk_add_f32 v[50:51], v[50:51], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
-        "v_pk_mul_f32 v[58:59], v[44:45], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
-        "v_pk_mul_f32 v[60:61], v[46:47], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
-        "v_pk_mul_f32 v[62:63], v[50:51], %[py] op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
-        "v_pk_fma_f32 v[44:45], %[px], v[58:59], v[44:45] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[46:47], %[pz], v[60:61], v[46:47] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[50:51], %[py], v[62:63], v[50:51] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[44:45], v[44:45], %[px], v[58:59] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
-        "v_pk_fma_f32 v[46:47], v[46:47], %[pz], v[60:61] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
-        "v_pk_fma_f32 v[50:51], v[50:51], %[py], v[62:63] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t" \
+        SLABS \
         "v_min_f32 v58, v40, v41\n\t" \
         "v_min_f32 v59, v48, v49\n\t" \
         "v_min_f32 v60, v42, v43\n\t" \
@@ -465,7 +497,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
           [tp] "s"(top_pairs), [amin] "s"(active_min), [ox] "s"(p.ox), [oz] "s"(p.oz) \
         : "memory", "scc", "vcc", R7_CLOBBERS
 
-template <bool OCL, int LEAFP>
+template <int FL, int LEAFP>
 __device__ __forceinline__ int run7(Lane6& L, const ExtendParams& p, uint32_t stack_base, uint32_t top_base,
                                     uint32_t top_pairs, unsigned long long special_mask, int& km,
                                     unsigned long long full, int active_min)
@@ -479,8 +511,12 @@ __device__ __forceinline__ int run7(Lane6& L, const ExtendParams& p, uint32_t st
     float dist = L.po.y;
     const float oy = L.po.x;
     static_assert(PS6 == 8, "run7 compares the stack pointer with the literal PS6 - 1");
-    if constexpr (OCL) asm volatile(R7_BODY(R7_TRI(R7_CROSS_OCL, R7_DOT_OCL)) R7_OPERANDS);
-    else asm volatile(R7_BODY(R7_TRI(R7_CROSS_STRICT, R7_DOT_STRICT)) R7_OPERANDS);
+    if constexpr (FL == 2)
+        asm volatile(R7_BODY(R7_TRI(R7_CROSS_OCL, R7_DOT_OCL, R7_NEWTON_NONE, R7_GO_A_SHIPPED, R7_GO_01_SHIPPED), R7_SLABS_SHIPPED) R7_OPERANDS);
+    else if constexpr (FL == 1)
+        asm volatile(R7_BODY(R7_TRI(R7_CROSS_OCL, R7_DOT_OCL, R7_NEWTON_EXACT, R7_GO_A_STRICT, R7_GO_01_STRICT), R7_SLABS_EXACT) R7_OPERANDS);
+    else
+        asm volatile(R7_BODY(R7_TRI(R7_CROSS_STRICT, R7_DOT_STRICT, R7_NEWTON_EXACT, R7_GO_A_STRICT, R7_GO_01_STRICT), R7_SLABS_EXACT) R7_OPERANDS);
     L.po.y = dist;
     return code;
 }
@@ -499,7 +535,7 @@ __device__ __forceinline__ bool outside_proof_conditions(float4 rec)
     return worst > one - lo || (uo != 0u && uo - ylo > yhi - ylo);
 }
 
-template <int LEAFP, bool RECORD, bool TOP, bool OCL>
+template <int LEAFP, bool RECORD, bool TOP, int FL>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
     __shared__ uint32_t s_stack[PS6 + 1][256];                      // 9 KB: row 0 always holds REF_DONE ("entry -1"), the stack proper follows
@@ -566,8 +602,8 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             // every loop-carried scalar whose update depends on them, as divergent and keeps them in vector registers)
             // (two call sites: a select between the two thresholds would drag `cursor` into a vector register)
             int why;
-            if (cursor < chunk_end) why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 64 - refill_c);
-            else why = run7<OCL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 0);
+            if (cursor < chunk_end) why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 64 - refill_c);
+            else why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 0);
             why = __builtin_amdgcn_readfirstlane(why);
             kflag = __builtin_amdgcn_readfirstlane(kflag);
             if (why == 1) {
@@ -603,16 +639,16 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                             set_in_place(plane_off, pl * p.plane_stride);
                             const float4 rec = p.rays[my];
                             // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
-                            // and never use y)
-                            set_in_place(L.px, rec.x, rcp_exact(rec.x));
-                            set_in_place(L.py, rec.y, rcp_exact(rec.y));
-                            set_in_place(L.pz, rec.z, rcp_exact(rec.z));
+                            // and never use y); flavour 2: y = v_rcp_f32(d), used by every lane
+                            set_in_place(L.px, rec.x, FL == 2 ? rcp_raw(rec.x) : rcp_exact(rec.x));
+                            set_in_place(L.py, rec.y, FL == 2 ? rcp_raw(rec.y) : rcp_exact(rec.y));
+                            set_in_place(L.pz, rec.z, FL == 2 ? rcp_raw(rec.z) : rcp_exact(rec.z));
                             set_in_place(L.po, rec.w, 1e30f);       // generate.cl:34-35
                             set_in_place(L.triID, 0u);
                             if (RECORD) { slot = my; live = true; }
                             set_in_place(L.sp, 0);
                             set_in_place(L.cur, root6);
-                            spec = outside_proof_conditions(rec) || p.force_exact != 0;
+                            spec = FL != 2 && (outside_proof_conditions(rec) || p.force_exact != 0);
                         }
                     }
                     cursor += (uint32_t)nidle;
@@ -628,8 +664,8 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             kflag = ~kflag;
             // (two specialisations of the general step -- hipcc's register allocation for the one with both
             // arithmetic forms does not fit beside the registers run7 reserves)
-            if ((special_mask & (m_in | m_lf)) != 0) step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, true, m_in | m_lf);
-            else step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, leaf_trip, false, m_in | m_lf);
+            if ((special_mask & (m_in | m_lf)) != 0) step6<TOP, FL>(L, p, stack_base, s_top, top_pairs, leaf_trip, true, m_in | m_lf);
+            else step6<TOP, FL>(L, p, stack_base, s_top, top_pairs, leaf_trip, false, m_in | m_lf);
         }
     } else
     for (;;) {
@@ -669,16 +705,16 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                         set_in_place(plane_off, pl * p.plane_stride);
                         const float4 rec = p.rays[my];
                         // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
-                        // and never use y)
-                        set_in_place(L.px, rec.x, rcp_exact(rec.x));
-                        set_in_place(L.py, rec.y, rcp_exact(rec.y));
-                        set_in_place(L.pz, rec.z, rcp_exact(rec.z));
+                        // and never use y); flavour 2: y = v_rcp_f32(d), used by every lane
+                        set_in_place(L.px, rec.x, FL == 2 ? rcp_raw(rec.x) : rcp_exact(rec.x));
+                        set_in_place(L.py, rec.y, FL == 2 ? rcp_raw(rec.y) : rcp_exact(rec.y));
+                        set_in_place(L.pz, rec.z, FL == 2 ? rcp_raw(rec.z) : rcp_exact(rec.z));
                         set_in_place(L.po, rec.w, 1e30f);       // generate.cl:34-35
                         set_in_place(L.triID, 0u);
                         if (RECORD) { slot = my; live = true; }
                         set_in_place(L.sp, 0);
                         set_in_place(L.cur, root6);
-                        spec = outside_proof_conditions(rec) || p.force_exact != 0;
+                        spec = FL != 2 && (outside_proof_conditions(rec) || p.force_exact != 0);
                     }
                 }
                 cursor += (uint32_t)nidle;
@@ -724,16 +760,16 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 #ifdef UVRT_TRIP_STATS
             const unsigned long long t0_ = __builtin_readcyclecounter();
 #endif
-            step6<TOP, OCL>(L, p, stack_base, s_top, top_pairs, kme != 0, (special_mask & (m_in | m_lf)) != 0, m_in | m_lf);
+            step6<TOP, FL>(L, p, stack_base, s_top, top_pairs, kme != 0, (special_mask & (m_in | m_lf)) != 0, m_in | m_lf);
 #ifdef UVRT_TRIP_STATS
             clk4 += (uint32_t)(__builtin_readcyclecounter() - t0_);
             ++st_slow;
 #endif
         } else
 #ifdef UVRT_TRIP_STATS
-            step7<TOP, OCL>(L, p, stack_base, top_base, m_in, m_lf & kme, m_top, full, clk);
+            step7<TOP, FL>(L, p, stack_base, top_base, m_in, m_lf & kme, m_top, full, clk);
 #else
-            step7<TOP, OCL>(L, p, stack_base, top_base, m_in, m_lf & kme, m_top, full);
+            step7<TOP, FL>(L, p, stack_base, top_base, m_in, m_lf & kme, m_top, full);
 #endif
     }
 #ifdef UVRT_TRIP_STATS
@@ -823,13 +859,14 @@ bool launch_extend6(const ExtendParams& p0, int code, int grid_per_cu, hipStream
     if (p.npairs > 0 && !p.recs_prepared)
         hipLaunchKernelGGL(k_prepare_launch6, dim3((unsigned)((p.npairs + 255) / 256)), dim3(256), 0, s,
                            p.scene.pairs, (float4*)p.recs, p.ox, p.oz, p.npairs, p.perm);
-#define UVRT_L6K(LP, REC, TOP, OCL) hipLaunchKernelGGL((k_extend6<LP, REC, TOP, OCL>), dim3(grid), dim3(256), 0, s, p)
+#define UVRT_L6K(LP, REC, TOP, FL) hipLaunchKernelGGL((k_extend6<LP, REC, TOP, FL>), dim3(grid), dim3(256), 0, s, p)
 #define UVRT_L6(LP, TOP)                                                                             \
     do {                                                                                             \
-        if (p.flavour) { if (p.hits) UVRT_L6K(LP, true, TOP, true); else UVRT_L6K(LP, false, TOP, true); }   \
-        else { if (p.hits) UVRT_L6K(LP, true, TOP, false); else UVRT_L6K(LP, false, TOP, false); }          \
+        if (p.flavour == 2) { if (p.hits) UVRT_L6K(LP, true, TOP, 2); else UVRT_L6K(LP, false, TOP, 2); }        \
+        else if (p.flavour) { if (p.hits) UVRT_L6K(LP, true, TOP, 1); else UVRT_L6K(LP, false, TOP, 1); }       \
+        else { if (p.hits) UVRT_L6K(LP, true, TOP, 0); else UVRT_L6K(LP, false, TOP, 0); }                     \
     } while (0)
-#ifdef UVRT_DEV_VARIANTS     // developer build (make dev -> libuvrt_hip_dev.so): every leaf period, with / without the LDS cache
+#ifdef UVRT_DEV_VARIANTS     // developer build (`make` builds it as libuvrt_hip_dev.so): every leaf period, with / without the LDS cache
     switch (code & 7) {
         case 0: UVRT_L6(1, true); break;
         case 1: UVRT_L6(2, true); break;

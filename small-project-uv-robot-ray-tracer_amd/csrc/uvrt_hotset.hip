@@ -2,7 +2,7 @@
 //
 // The traversal kernel (uvrt_extend6.hip) serves the first records of its numbering from LDS.  Which
 // records are hot depends on the lamp: the 127 most visited ones take 62-70 % of all inner-node visits on
-// the test room (the cache holds 175), the first 127 in breadth-first order 31-40 % (profiles/r02_record_layout_experiment.txt).
+// the test room (the cache holds 175), the first 127 in breadth-first order 31-40 % (profiles/r02/r02_record_layout_experiment.txt).
 // For every new lamp position the context therefore enqueues three small kernels on the launch's stream (the new lamps of
 // one uvrt_trace_batch call share ONE launch of each: blockIdx.y = the lamp):
 //   1. k_visit_stats -- traces a sample of the launch's own photons (global ids [0, S)): a plain
@@ -49,7 +49,7 @@ __device__ __forceinline__ bool box_approx(float mnx, float mny, float mnz, floa
 }
 
 // (Workgroups of 128 or 64 threads, spread over twice / four times as many CUs, are no faster: 98 / 106 us against 97 us --
-// the kernel lasts as long as the dependent fetches of its longest rays, profiles/r03_hot_setup_sweep.txt.)
+// the kernel lasts as long as the dependent fetches of its longest rays, profiles/r03/r03_hot_setup_sweep.txt.)
 constexpr int HS_THREADS = 256;
 __global__ __launch_bounds__(HS_THREADS) void k_visit_stats(StatParams p)
 {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(HS_THREADS) void k_visit_stats(StatParams p)
     // stragglers: it stops when at most p.tail_lanes of its rays are still under way (16 of 64: the slowest quarter of the
     // rays takes half as many steps again as the rest; what those would still visit does not change which records are hot --
     // coverage of the true best 175 over the route's 12 lamps 0.9989-0.9999 with 16, 0.9994-0.9999 with 6, and 10 % less
-    // time; profiles/r03_hot_setup_sweep.txt).
+    // time; profiles/r03/r03_hot_setup_sweep.txt).
     for (int it = 0; it < HS_MAX_STEPS && cur != REF_DONE; ++it) {
         if (it >= 32 && __popcll(__builtin_amdgcn_ballot_w64(true)) <= p.tail_lanes) break;     // (the lanes still in the loop)
         const bool leaf = cur >= REF_LEAF_BIT;

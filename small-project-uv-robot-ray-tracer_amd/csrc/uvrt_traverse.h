@@ -17,7 +17,7 @@ constexpr int PS6 = 8;                    // LDS stack entries per lane.  7.5 % 
                                           // launch pipelining lives on the eighth workgroup slot of a CU
 constexpr uint32_t TOP6_STRIDE = 64;      // bytes per cached record.  (80 with 16 bytes of padding spread the lanes of a
                                           // ds_read_b128 over more banks, but LDS reads cost a trip nothing measurable and 48
-                                          // more records do: +2 %, profiles/r02_experiments.txt)
+                                          // more records do: +2 %, profiles/r02/r02_experiments.txt)
 
 // The six slab distances of one child box (extend.cl:31-37), correctly rounded:
 //   t = a / d  as  q0 = a * y;  r = fma(-d, q0, a);  q = fma(r, y, q0),   y = RN32(1/d)
@@ -39,6 +39,18 @@ __device__ __forceinline__ void slabs6(v2f& x, v2f& y, v2f& z, v2f px, v2f py, v
         "v_pk_fma_f32 %[z], %[z], %[pz], %[tz] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
         "v_pk_fma_f32 %[y], %[y], %[py], %[ty] op_sel:[0,1,0] op_sel_hi:[1,1,1]"
         : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz)
+        : [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [po] "v"(po));
+}
+
+// The same six distances in the "shipped flags" flavour (uvrt_set_flavour 2): t = (b - o) * v_rcp_f32(d), with the
+// reciprocal in the high half of px / py / pz -- what the reference's own build flags make of extend.cl:31-35
+__device__ __forceinline__ void slabs6s(v2f& x, v2f& y, v2f& z, v2f px, v2f py, v2f pz, v2f po)
+{
+    asm("v_pk_add_f32 %[y], %[y], %[po] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[x], %[x], %[px] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[z], %[z], %[pz] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[y], %[y], %[py] op_sel:[0,1] op_sel_hi:[1,1]"
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z)
         : [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [po] "v"(po));
 }
 
@@ -112,47 +124,71 @@ __device__ __forceinline__ float rcp_exact(float a)
     return __builtin_fmaf(e, y0, y0);
 }
 
+// v_rcp_f32 as it is (about 1 ulp): the reciprocal of the "shipped flags" flavour
+__device__ __forceinline__ float rcp_raw(float a)
+{
+    float y;
+    asm("v_rcp_f32 %0, %1" : "=v"(y) : "v"(a));
+    return y;
+}
+
 // extend.cl:6-27 on a leaf record (v0, e1 = v1 - v0, e2 = v2 - v0, id in v0.w).
-// OCL = the "ocl-amd" flavour (include/uvrt.h uvrt_set_flavour): cross() and dot() in the fused forms
-// ROCm's OpenCL device library gives the reference's extend.cl on gfx950 (read off the disassembly of
-// that kernel as built for gfx950): cross(a, b).x = fma(a.y, b.z, -(a.z * b.y)), dot(a, b) = fma(a.z, b.z,
-// fma(a.y, b.y, a.x * b.x)); everything else as extend.cl writes it.
-template <bool OCL>
+// FL = the arithmetic flavour (include/uvrt.h uvrt_set_flavour):
+//   0  strict: every operator one rounding, source order;
+//   1  "ocl-amd": cross() and dot() in the fused forms ROCm's OpenCL device library gives the reference's
+//      extend.cl on gfx950 (read off the disassembly of that kernel as built for gfx950):
+//      cross(a, b).x = fma(a.y, b.z, -(a.z * b.y)), dot(a, b) = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+//      everything else as extend.cl writes it;
+//   2  "shipped flags": what the reference's OWN build options (-cl-fast-relaxed-math -cl-mad-enable,
+//      template/template.cpp:1192) make of extend.cl on gfx950 (read off the disassembly of that build, which the tests run live beside this): the
+//      fused forms of flavour 1, f = v_rcp_f32(a) without refinement, and the early returns in the forms the
+//      no-NaN licence gives them (|a| >= 1e-5, 0 <= u, 1 >= u, 0 <= v, 1 >= v + u continue).
+template <int FL>
 __device__ __forceinline__ float cross6(float ay, float bz, float az, float by)
 {
-    return OCL ? __builtin_fmaf(ay, bz, -(az * by)) : ay * bz - az * by;
+    return FL != 0 ? __builtin_fmaf(ay, bz, -(az * by)) : ay * bz - az * by;
 }
-template <bool OCL>
+template <int FL>
 __device__ __forceinline__ float dot6(float ax, float ay, float az, float bx, float by, float bz)
 {
-    return OCL ? __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx)) : ax * bx + ay * by + az * bz;
+    return FL != 0 ? __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx)) : ax * bx + ay * by + az * bz;
 }
-template <bool OCL>
+template <int FL>
 __device__ __forceinline__ void tri6(float ox, float oy, float oz, float dx, float dy, float dz, float& dist,
                                      uint32_t& triID, const float4 v0, const float4 e1, const float4 e2,
                                      bool exact)
 {
-    const float hx = cross6<OCL>(dy, e2.z, dz, e2.y);
-    const float hy = cross6<OCL>(dz, e2.x, dx, e2.z);
-    const float hz = cross6<OCL>(dx, e2.y, dy, e2.x);
-    const float a = dot6<OCL>(e1.x, e1.y, e1.z, hx, hy, hz);
-    if (fabsf(a) < 0.00001f) return;
+    const float hx = cross6<FL>(dy, e2.z, dz, e2.y);
+    const float hy = cross6<FL>(dz, e2.x, dx, e2.z);
+    const float hz = cross6<FL>(dx, e2.y, dy, e2.x);
+    const float a = dot6<FL>(e1.x, e1.y, e1.z, hx, hy, hz);
+    if (FL == 2 ? !(fabsf(a) >= 0.00001f) : fabsf(a) < 0.00001f) return;
     float f;
-    if (exact) f = 1.0f / a;         // wave-uniform
+    if (FL == 2) f = rcp_raw(a);
+    else if (exact) f = 1.0f / a;         // wave-uniform
     else f = rcp_exact(a);
     const float sx = ox - v0.x, sy = oy - v0.y, sz = oz - v0.z;
-    const float u = f * dot6<OCL>(sx, sy, sz, hx, hy, hz);
-    if ((u < 0) | (u > 1)) return;
-    const float qx = cross6<OCL>(sy, e1.z, sz, e1.y);
-    const float qy = cross6<OCL>(sz, e1.x, sx, e1.z);
-    const float qz = cross6<OCL>(sx, e1.y, sy, e1.x);
-    const float v = f * dot6<OCL>(dx, dy, dz, qx, qy, qz);
-    if ((v < 0) | (u + v > 1)) return;
-    const float tt = f * dot6<OCL>(e2.x, e2.y, e2.z, qx, qy, qz);
+    const float u = f * dot6<FL>(sx, sy, sz, hx, hy, hz);
+    if (FL == 2 ? !((0.0f <= u) & (1.0f >= u)) : ((u < 0) | (u > 1))) return;
+    const float qx = cross6<FL>(sy, e1.z, sz, e1.y);
+    const float qy = cross6<FL>(sz, e1.x, sx, e1.z);
+    const float qz = cross6<FL>(sx, e1.y, sy, e1.x);
+    const float v = f * dot6<FL>(dx, dy, dz, qx, qy, qz);
+    if (FL == 2 ? !((0.0f <= v) & (1.0f >= u + v)) : ((v < 0) | (u + v > 1))) return;
+    const float tt = f * dot6<FL>(e2.x, e2.y, e2.z, qx, qy, qz);
     if (tt > 0.0001f && tt < dist) {
         dist = tt;
         triID = __float_as_uint(v0.w);
     }
+}
+
+// extend.cl:29-38 in the "shipped flags" flavour: t = (b - o) * v_rcp_f32(d) (the numerators arrive as b - o, the
+// reciprocals in the ray's {d, rcp} pairs), then the same hardware min / max as box_fast
+__device__ __forceinline__ bool box_shipped(float ax1, float ax2, float ay1, float ay2, float az1, float az2,
+                                            float rx, float ry, float rz, float dist, float& tmin)
+{
+    const v2f tx = {ax1 * rx, ax2 * rx}, ty = {ay1 * ry, ay2 * ry}, tz = {az1 * rz, az2 * rz};
+    return box_fast(tx, ty, tz, dist, tmin);
 }
 
 // In-place update of a loop-carried value inside a divergent branch: the write happens under the

@@ -88,6 +88,52 @@ def test_batch_equals_the_per_launch_sequence_and_the_oracle(pkg, orc, oscene, o
         b.close()
 
 
+def test_a_new_record_renumbering_at_the_same_address_is_not_mistaken_for_the_old_one(pkg, orc, oscene, oroute):
+    """uvrt_set_record_perm(P1), batch, uvrt_set_record_perm(P2) with the same n -- the context's buffer keeps
+    its address -- then a batch from the SAME lamp column: the per-launch records must be re-laid for P2 (the kernel
+    starts at P2[root]); 70 lamps through the 64-entry hot cache make an entry be recycled under a key that matches too."""
+    n = 40000
+    length = oroute["lightLength"]
+    lp = lamp_pos(orc, oscene, oroute, 0)
+    rng = np.random.default_rng(5)
+    c = pkg.capi.Ctx(0)
+    try:
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        nodes = oscene.nodes                                     # inner nodes reachable from the root
+        q, i = [0], 0
+        while i < len(q):
+            l = int(nodes[q[i]]["leftFirst"]); i += 1
+            q += [l + k for k in (0, 1) if nodes[l + k]["triCount"] == 0]
+        npairs = len(q)
+        expect = []
+        seed = 0
+        for _ in range(3):
+            rays, seed2 = orc.generate(0, n, lp, length, seed)
+            temp = np.zeros(oscene.T, dtype=np.int32)
+            orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+            expect.append(temp)
+            seed = seed2
+        c.seed = 0
+        for k, perm in enumerate([rng.permutation(npairs), rng.permutation(npairs), None]):
+            c.set_record_perm(None if perm is None else perm.astype(np.uint32))
+            c.trace_batch([lp], length, 0, n)
+            got = c.read_batch_counts(0)
+            c.replay_batch(make_ops(pkg, [1.0], {}, n))
+            assert np.array_equal(got, expect[k]), "batch %d traced against stale records" % k
+        # hot entries: 70 distinct lamps through the 64-entry cache, then the first lamp again
+        c.seed = 0
+        for j in range(70):
+            q = (lp[0] + 0.001 * (j + 1), lp[1], lp[2])
+            c.trace_batch([q], length, 0, 20000)
+            c.replay_batch(make_ops(pkg, [1.0], {}, 20000))
+        c.seed = 0
+        c.trace_batch([lp], length, 0, n)
+        assert np.array_equal(c.read_batch_counts(0), expect[0])
+        c.replay_batch(make_ops(pkg, [1.0], {}, n))
+    finally:
+        c.close()
+
+
 def test_batch_call_order_errors_and_reset(pkg, orc, oscene, oroute):
     c = pkg.capi.Ctx(0)
     try:

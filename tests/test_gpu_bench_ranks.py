@@ -48,3 +48,37 @@ def test_two_rank_rehearsal_matches_single_rank():
     for d in (one, two, three):
         assert d["roofline"] is None or 0.0 < d["roofline"]["frac"] <= 1.0
         assert d["unit"] == "Mray/s" and d["higher_is_better"] is True
+
+
+def test_bench_starts_its_own_ranks_and_labels_the_rehearsal():
+    """`python3 bench.py --gpus 2 --steps 5` -- no launcher, no WORLD_SIZE -- must produce a line by
+    itself (the parent touches no GPU and starts one child per rank); on a 1-GPU box that is the gloo REHEARSAL, whose
+    dose CRC equals the N = 1 CRC."""
+    common = ["--photons", "200000", "--warmup", "1", "--no-cpu-baseline", "--waves", "4"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"] + common,
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0's line only
+    two = json.loads(lines[0])
+    one = bench(common + ["--steps", "1", "--lean"])
+    assert two["n_gpus"] == 2 and two["steps"] == 5 and two["comm"].startswith("REHEARSAL")
+    assert two["dose_crc32"] == one["dose_crc32"] and two["ranks_agree"] is True
+    assert two["strong"]["dose_crc32"] == one["dose_crc32"] and two["weak"] is not None
+    assert one["comm"] is None and one["rccl_ranks"] is None and one["reserved_cus"] == 0
+
+
+def test_single_rank_rehearsals_of_both_collective_branches():
+    """The N > 1 step with the context's own RCCL communicator (uvrt_reduce_batch) and with torch.distributed's RCCL
+    all-reduce of the device planes (the fallback branch) -- each run for real with the one rank a 1-GPU box allows:
+    same dose bits as the plain step, and RCCL itself reports the communicator's span."""
+    common = ["--photons", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--waves", "4", "--lean"]
+    plain = bench(common)
+    native = bench(common + ["--self-comm"])
+    fallback = bench(common + ["--self-comm", "--comm", "torch"])
+    assert native["comm"] == "native" and native["rccl_ranks"] == 1 and native["reserved_cus"] in (0, 8)
+    assert fallback["comm"] == "torch" and fallback["rccl_ranks"] == 1 and fallback["reserved_cus"] == 0
+    assert native["dose_crc32"] == plain["dose_crc32"] == fallback["dose_crc32"]

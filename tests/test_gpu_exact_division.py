@@ -1,6 +1,6 @@
 """GPU: the two arithmetic identities the default extend kernel rests on, checked on the hardware
-itself by the exhaustive tools under tests/tools/ (full runs: profiles/r01_div3_exhaustive.log,
-profiles/r01_rcp_exhaustive.log).  Here: every 512th divisor significand against all 2^23 dividend
+itself by the exhaustive tools under tests/tools/ (full runs: profiles/r01/r01_div3_exhaustive.log,
+profiles/r01/r01_rcp_exhaustive.log).  Here: every 512th divisor significand against all 2^23 dividend
 significands (1.4e11 pairs), and the reciprocal for all 2^31 values of its range."""
 import os
 import shutil

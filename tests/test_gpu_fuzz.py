@@ -1,5 +1,5 @@
 """GPU: randomised differential test -- small random scenes (the oracle's BVH builder: bvh.cpp's order), random lamp
-positions, ray counts that are not multiples of 64, both arithmetic flavours and both SEED semantics, through the three
+positions, ray counts that are not multiples of 64, the three arithmetic flavours and both SEED semantics, through the three
 ways the product traces (per-launch calls with and without launch pipelining, batched tracing with its fused launches).
 Everything against the oracle, bit for bit: per-ray (dist, triID) where the path records them, counts, maps, dose.  The
 generator is seeded: a failure names its case."""
@@ -44,6 +44,12 @@ def test_random_scene_lamp_and_launch_shape(pkg, orc, case):
     T = tris.shape[0]
     nodes, idx = orc.build_bvh(tris)
     flavour = int(rng.integers(0, 2))
+    if case % 4 == 3:
+        # the "shipped flags" arithmetic (uvrt_set_flavour 2): the oracle follows through its model of v_rcp_f32, whose table
+        # is read from this GPU (oracle/rcp_model.h; checked exhaustively in test_gpu_shipped_flags.py)
+        flavour = 2
+        if orc.refgpu() is None:
+            flavour = 1
     seed_mode = int(rng.integers(0, 2))
     n = int(rng.choice([1, 63, 64, 65, 1000, 20001, 70000]))
     launches = int(rng.integers(1, 5))

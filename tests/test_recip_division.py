@@ -72,7 +72,7 @@ def test_special_values():
 # ------------------------------------------------------------------------------------------------
 # extend v5/v6: the packed f32 form  q0 = a*y; r = fma(-d, q0, a); q = fma(r, y, q0),  y = RN32(1/d)
 # (csrc/uvrt_extend6.hip).  The proof is the exhaustive GPU run (tests/tools/div3_exhaustive.hip,
-# profiles/r01_div3_exhaustive.log); this is the same check on the CPU (glibc fmaf is exact) over
+# profiles/r01/r01_div3_exhaustive.log); this is the same check on the CPU (glibc fmaf is exact) over
 # random, extreme-divisor and next-to-midpoint operands.
 _C_SRC = r"""
 #include <math.h>

@@ -4,7 +4,7 @@
     python tests/tools/isa_cost.py <file.s> <kernel-symbol-substring> [--blocks]
 
 <file.s> is `hipcc -S --cuda-device-only` output.  Every instruction gets the issue cost measured by
-tests/tools/valu_calib.hip on an MI355X at 8 waves per SIMD (profiles/r02_valu_calibration.txt):
+tests/tools/valu_calib.hip on an MI355X at 8 waves per SIMD (profiles/r02/r02_valu_calibration.txt):
 
     2 cycles  v_fma/fmac/mul/add/sub_f32, v_mov_b32, v_and/or/xor_b32, v_lshrrev_b32, v_add/sub_u32
     4 cycles  every packed f32 op (v_pk_*), v_min/max/min3/max3/med3_f32, every v_cmp, v_cndmask,

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Developer tool: turn a PMC summary of the extend kernel (tests/tools/pmc_extend.sh) and the issue-rate
-calibration (tests/tools/valu_calib.hip, profiles/r02_valu_calibration.txt) into the per-launch resource
+calibration (tests/tools/valu_calib.hip, profiles/r02/r02_valu_calibration.txt) into the per-launch resource
 model bench.py's `roofline` prices a launch with.
 
     python tests/tools/issue_model.py <summary.txt> <out.json> [rays_per_launch] [note]
 
-Calibrated constants (MI355X, 8 waves per SIMD, profiles/r02_*calibration*.txt):
+Calibrated constants (MI355X, 8 waves per SIMD, profiles/r02/r02_*calibration*.txt):
   * VALU issue, cycles per wave64 instruction per SIMD: 2 for v_fma/mul/add/sub_f32, v_mov, v_and/or/xor,
     v_add/sub_u32, v_lshrrev; 4 for every packed f32 op, v_min/max/min3/max3, every v_cmp, v_cndmask, shifts
     left, 24/32-bit multiplies, three-operand integer ops and any VALU op with an SGPR source; 8 for v_rcp_f32.
