@@ -24,6 +24,10 @@ g.load_package()
 from uvrt_amd import host  # noqa: E402
 
 variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+# FLAVOURS=0,2: every variant in each of these arithmetic flavours (uvrt_set_flavour), interleaved like the variants; a
+# cell is then named 10000 * flavour + variant.  The dose CRC must agree within a flavour.
+flavours = [int(v) for v in os.environ.get("FLAVOURS", os.environ.get("FLAVOUR", "0")).split(",")]
+cells = [(f, v) for f in flavours for v in variants]
 mode = os.environ.get("MODE", "batched")
 steps = int(os.environ.get("STEPS", "20"))
 rounds = int(os.environ.get("ROUNDS", "5"))
@@ -44,7 +48,6 @@ else:
 rt.set_lamps(rt.lamps()[:nlamps])
 rt.photonCount = photons * nlamps
 rt.maxIterations = waves
-rt.ctx.set_flavour(int(os.environ.get("FLAVOUR", "0")))
 if os.environ.get("WIDE", "0") == "1":
     rt.ctx.set_wide_bvh(True)
 rays_per_step = waves * rt.photonsPerLight * nlamps
@@ -64,11 +67,13 @@ def step():
                 rt.Sync()
 
 
-res = {v: [] for v in variants}
+res = {c: [] for c in cells}
 crcs = {}
 iso = {}
 for rnd in range(rounds + 1):                 # round 0 = warm-up (allocations, hot records, clocks)
-    for v in variants:
+    for c in cells:
+        f, v = c
+        rt.ctx.set_flavour(f)
         rt.ctx.set_variant(v)
         step()
         rt.Sync()
@@ -78,12 +83,14 @@ for rnd in range(rounds + 1):                 # round 0 = warm-up (allocations, 
         rt.Sync()
         el = time.perf_counter() - t0
         if rnd > 0:
-            res[v].append(rays_per_step * steps / el / 1e6)
-        crcs[v] = "%08x" % zlib.crc32(rt.read_dosage().tobytes())
+            res[c].append(rays_per_step * steps / el / 1e6)
+        crcs[c] = "%08x" % zlib.crc32(rt.read_dosage().tobytes())
 if os.environ.get("ISOLATED", "0") == "1":
     rt.ctx.set_pipeline(False)
     for rnd in range(3):
-        for v in variants:
+        for c in cells:
+            f, v = c
+            rt.ctx.set_flavour(f)
             rt.ctx.set_variant(v)
             rt.ctx.set_timing(True)
             rt.ctx.extend_time_ms()
@@ -94,16 +101,17 @@ if os.environ.get("ISOLATED", "0") == "1":
             rt.Sync()
             ms, k = rt.ctx.extend_time_ms()
             rt.ctx.set_timing(False)
-            iso.setdefault(v, []).append(ms / max(k, 1))
+            iso.setdefault(c, []).append(ms / max(k, 1))
     rt.ctx.set_pipeline(True)
-base = np.median(res[variants[0]])
-for v in variants:
-    a = np.array(res[v])
-    line = "variant %5d  %s  median %8.1f  best %8.1f  min %8.1f Mray/s  (%+.2f %% vs %d)  crc %s" % (
-        v, mode, np.median(a), a.max(), a.min(), 100.0 * (np.median(a) / base - 1.0), variants[0], crcs[v])
-    if v in iso:
-        line += "  isolated extend %.4f ms" % min(iso[v])
+base = np.median(res[cells[0]])
+for c in cells:
+    a = np.array(res[c])
+    line = "variant %5d flavour %d  %s  median %8.1f  best %8.1f  min %8.1f Mray/s  (%+.2f %% vs the first)  crc %s" % (
+        c[1], c[0], mode, np.median(a), a.max(), a.min(), 100.0 * (np.median(a) / base - 1.0), crcs[c])
+    if c in iso:
+        line += "  isolated extend %.4f ms" % min(iso[c])
     print(line, flush=True)
-if len(set(crcs.values())) != 1:
-    print("DOSE MISMATCH between variants", crcs)
-    sys.exit(1)
+for f in flavours:
+    if len({crcs[c] for c in cells if c[0] == f}) != 1:
+        print("DOSE MISMATCH between variants of flavour", f, crcs)
+        sys.exit(1)
