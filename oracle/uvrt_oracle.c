@@ -399,6 +399,146 @@ void orc_extend_visit_hist(const orc_tri* tris, const orc_ray* rays, int64_t n, 
     }
 }
 
+/* Analysis helper (tests/tools/wave_sim.py): the persistent-wave scheduler of the HIP kernel replayed on the CPU with the real
+ * arithmetic -- 64 lanes per wave, one traversal step per lane and trip, refill when `refill_min` lanes are idle.
+ *   mode 0 = the kernel as it is: a lane at a leaf tests its triangles on a leaf trip (every second trip, or any trip
+ *            without a lane at an inner node) and waits otherwise;
+ *   mode 1 = the deferred triangle queue: a lane at a leaf appends (lane, leaf) to a per-wave queue,
+ *            pops and goes on with its CURRENT (stale) dist; the queue is flushed -- entries tested in queue order, ceil(count /
+ *            64) full-width triangle blocks -- when it holds >= queue_flush entries, before a refill, or when no lane stands
+ *            at an inner node.
+ * Counts trips, triangle-block executions, lane visits, and how many rays end with another (dist, triID) than the
+ * reference's traversal gives (mode 1 is not exact by construction: a stale dist adds box visits, and a triangle's computed
+ * t can undercut the computed entry distance of a box that the reference culled). */
+typedef struct {
+    uint64_t rays, trips, inner_trips, leaf_blocks, inner_lane_visits, leaf_lane_tests, wait_lane_trips, idle_lane_trips,
+             refills, flushes, queue_entries, differ_tri, differ_dist, ref_inner_visits, ref_tri_tests;
+} orc_wavesim;
+
+typedef struct { int64_t ray; const orc_node* cur; const orc_node* stack[32]; uint32_t sp; int active; orc_ray r; } sim_lane;
+
+void orc_wave_sim(const orc_tri* tris, const orc_ray* rays, int64_t n, const orc_node* nodes, const uint32_t* triIdx,
+                  int mode, int refill_min, int queue_flush, int rays_per_wave, orc_wavesim* out, int nthreads)
+{
+    orc_wavesim total;
+    memset(&total, 0, sizeof total);
+    const int64_t nwaves = (n + rays_per_wave - 1) / rays_per_wave;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads)
+    {
+        orc_wavesim st;
+        memset(&st, 0, sizeof st);
+        sim_lane* L = (sim_lane*)malloc(64 * sizeof(sim_lane));
+        struct { int lane; const orc_node* leaf; } queue[128];
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t w = 0; w < nwaves; w++) {
+            int64_t next = w * rays_per_wave;
+            const int64_t end = (w + 1) * rays_per_wave < n ? (w + 1) * rays_per_wave : n;
+            for (int l = 0; l < 64; l++) L[l].active = 0, L[l].cur = NULL;
+            int qn = 0, leaf_flag = 1;
+            for (;;) {
+                int idle = 0, inner = 0, atleaf = 0;
+                for (int l = 0; l < 64; l++) {
+                    if (!L[l].active || L[l].cur == NULL) idle++;
+                    else if (L[l].cur->triCount > 0) atleaf++;
+                    else inner++;
+                }
+                /* flush of the deferred queue */
+                const int want_refill = (next < end && idle >= refill_min) || (next >= end && idle == 64);
+                if (mode == 1 && qn > 0 && (qn >= queue_flush || want_refill || inner == 0)) {
+                    for (int q = 0; q < qn; q++) {
+                        sim_lane* o = &L[queue[q].lane];
+                        const orc_node* nd = queue[q].leaf;
+                        for (uint32_t i = 0; i < (uint32_t)nd->triCount; i++) {
+                            const uint32_t id = triIdx[nd->leftFirst + i];
+                            intersect_tri(&o->r, &tris[id], id);
+                        }
+                    }
+                    st.flushes++;
+                    st.leaf_blocks += (uint64_t)((qn + 63) / 64);
+                    st.queue_entries += (uint64_t)qn;
+                    qn = 0;
+                }
+                if (want_refill) {
+                    /* finished lanes: compare with the reference's own traversal, then take new rays */
+                    for (int l = 0; l < 64; l++) {
+                        if (L[l].active && L[l].cur == NULL) {
+                            orc_ray ref = rays[L[l].ray];
+                            orc_stats rs;
+                            memset(&rs, 0, sizeof rs);
+                            bvh_intersect(&ref, tris, nodes, triIdx, &rs);
+                            st.ref_inner_visits += rs.aabb_tests / 2;
+                            st.ref_tri_tests += rs.tri_tests;
+                            union { float f; uint32_t u; } a, b;
+                            a.f = ref.dist; b.f = L[l].r.dist;
+                            if (a.u != b.u) st.differ_dist++;
+                            if (ref.triID != L[l].r.triID && !(ref.dist == 1e30f && L[l].r.dist == 1e30f)) st.differ_tri++;
+                            L[l].active = 0;
+                            st.rays++;
+                        }
+                    }
+                    if (next >= end) break;
+                    for (int l = 0; l < 64 && next < end; l++) {
+                        if (L[l].active) continue;
+                        L[l].active = 1;
+                        L[l].ray = next;
+                        L[l].r = rays[next++];
+                        L[l].cur = &nodes[0];
+                        L[l].sp = 0;
+                    }
+                    st.refills++;
+                    continue;
+                }
+                /* one trip */
+                st.trips++;
+                if (inner) st.inner_trips++;
+                const int leaf_trip = mode == 0 ? (inner == 0 || leaf_flag) : 1;
+                leaf_flag = !leaf_flag;
+                int tested = 0;
+                for (int l = 0; l < 64; l++) {
+                    sim_lane* o = &L[l];
+                    if (!o->active || o->cur == NULL) { st.idle_lane_trips++; continue; }
+                    const orc_node* node = o->cur;
+                    if (node->triCount > 0) {
+                        if (mode == 0) {
+                            if (!leaf_trip) { st.wait_lane_trips++; continue; }
+                            for (uint32_t i = 0; i < (uint32_t)node->triCount; i++) {
+                                const uint32_t id = triIdx[node->leftFirst + i];
+                                intersect_tri(&o->r, &tris[id], id);
+                            }
+                            tested++;
+                        } else {
+                            queue[qn].lane = l; queue[qn].leaf = node; qn++;
+                        }
+                        st.leaf_lane_tests++;
+                        o->cur = o->sp ? o->stack[--o->sp] : NULL;
+                        continue;
+                    }
+                    st.inner_lane_visits++;
+                    const orc_node* c1 = &nodes[node->leftFirst];
+                    const orc_node* c2 = &nodes[node->leftFirst + 1];
+                    float d1 = intersect_aabb(&o->r, c1), d2 = intersect_aabb(&o->r, c2);
+                    if (d1 > d2) { float d = d1; d1 = d2; d2 = d; const orc_node* c = c1; c1 = c2; c2 = c; }
+                    if (d1 == 1e30f) o->cur = o->sp ? o->stack[--o->sp] : NULL;
+                    else { o->cur = c1; if (d2 != 1e30f) o->stack[o->sp++] = c2; }
+                }
+                if (mode == 0 && tested) st.leaf_blocks++;
+            }
+        }
+        free(L);
+#pragma omp critical
+        {
+            uint64_t* a = (uint64_t*)&total; const uint64_t* b = (const uint64_t*)&st;
+            for (size_t i = 0; i < sizeof(orc_wavesim) / 8; i++) a[i] += b[i];
+        }
+    }
+    *out = total;
+}
+
 /* ------------------------------------------------- accumulate / reset / shade kernels */
 
 void orc_accumulate(double* photonMap, double* maxPhotonMap, int32_t* temp, float timeStep,
