@@ -78,7 +78,8 @@ int uvrt_generate(uvrt_ctx* ctx, const float light_pos[3], float light_length,
  * then one increment of tempPhotonMap[triID] per hit. */
 int uvrt_extend(uvrt_ctx* ctx, int64_t n);
 
-/* cl/accumulate.cl:4-14 over tri_count triangles */
+/* cl/accumulate.cl:4-14 over tri_count triangles.  (A full-range accumulate is enqueued with the next call: a uvrt_shade
+ * right behind it -- the host loop's order, myapp.cpp:159-160 -- runs both in one kernel; same arithmetic, same order.) */
 int uvrt_accumulate(uvrt_ctx* ctx, float time_step, int32_t tri_count);
 
 /* cl/shade.cl:23-41 (computeDosage) over tri_count triangles */

@@ -77,7 +77,24 @@ int uvrt_create(int device_id, uvrt_ctx** out)
     if (const char* e = getenv("UVRT_HOT_SAMPLE")) { const int v = atoi(e); if (v >= 256 && v <= (1 << 20)) c->hot_sample = v; }
     if (const char* e = getenv("UVRT_HOT_DIRECT")) { const int v = atoi(e); if (v >= 0 && v <= 8192) c->hot_direct = v; }
     if (const char* e = getenv("UVRT_HOT_TAIL")) { const int v = atoi(e); if (v >= 0 && v < 64) c->hot_tail = v; }
-    int rc = c->error_flag.ensure(256, true, c->stream);      // the flag; a developer build keeps trip statistics behind it
+    int rc = c->error_flag.ensure(256, true, c->stream);      // (a developer build keeps trip statistics behind the flag)
+#ifndef UVRT_TRIP_STATS
+    // the stack-overflow flag lives in pinned host memory the kernels can write: uvrt_sync reads it after the stream sync
+    // instead of copying a device word back (a pageable 4-byte copy cost every sync ~10 us)
+    if (!rc) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            delete c;
+            return fail(UVRT_ERR_HIP, "uvrt_create: cannot allocate the pinned error flag");
+        }
+        memset(hp, 0, 64);
+        c->host_flag = (uint32_t*)hp;
+        c->host_flag_dev = (uint32_t*)dp;
+    }
+#endif
     // 256 CUs x 16 workgroups x 256 threads x 16 entries: the largest persistent grid
     if (!rc) rc = c->ovf_stack.ensure((size_t)OVF_MAX_ENTRIES * sizeof(uint32_t), false, c->stream);
     if (rc) { delete c; return rc; }
@@ -113,6 +130,7 @@ void uvrt_destroy(uvrt_ctx* c)
                       &c->ovf_stack, &c->error_flag})
         b->release();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->host_flag) (void)hipHostFree(c->host_flag);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -447,8 +465,13 @@ int uvrt_sync(uvrt_ctx* c)
     if (int rc = set_device(c)) return rc;
     if (int rc = join_all(c)) return rc;
     uint32_t flag = 0;
+#ifdef UVRT_TRIP_STATS
     HIP_TRY(hipMemcpyAsync(&flag, c->error_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+#else
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    flag = *(volatile uint32_t*)c->host_flag;
+#endif
 #ifdef UVRT_TRIP_STATS
     if (getenv("UVRT_TRIP_STATS")) {
         unsigned long long st[21];
@@ -471,7 +494,11 @@ int uvrt_sync(uvrt_ctx* c)
     }
 #endif
     if (flag) {
+#ifdef UVRT_TRIP_STATS
         HIP_TRY(hipMemsetAsync(c->error_flag.p, 0, 4, c->stream));
+#else
+        *(volatile uint32_t*)c->host_flag = 0u;
+#endif
         return fail(UVRT_ERR_STACK, "extend: BVH traversal needed more than 32 stack entries (extend.cl:43)");
     }
     return UVRT_OK;

@@ -198,7 +198,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.counts = S.planes.as<int32_t>() + (size_t)ph0 * plane_ints;
             p.count_replicas = R;
             p.count_stride = c->T;
-            p.error_flag = c->error_flag.as<uint32_t>();
+            p.error_flag = c->host_flag_dev ? c->host_flag_dev : c->error_flag.as<uint32_t>();
             p.ox = gx[g];
             p.oz = gz[g];
             p.n = (int64_t)kc * n_pad;

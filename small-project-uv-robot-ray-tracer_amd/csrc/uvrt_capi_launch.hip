@@ -275,7 +275,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     p.counts = lane_counts(c).as<int32_t>();
     p.count_replicas = c->replicas;
     p.count_stride = c->T;
-    p.error_flag = c->error_flag.as<uint32_t>();
+    p.error_flag = c->host_flag_dev ? c->host_flag_dev : c->error_flag.as<uint32_t>();
     p.ox = c->ox;
     p.oz = c->oz;
     p.n = n;
@@ -348,15 +348,23 @@ int uvrt_accumulate(uvrt_ctx* c, float time_step, int32_t tri_count)
 {
     if (!c || !c->have_scene || tri_count < 0 || tri_count > c->T)
         return fail(UVRT_ERR_INVALID, "uvrt_accumulate: bad tri_count");
-    if (int rc = set_device(c)) return rc;
+    if (int rc = set_device(c)) return rc;       // (an earlier deferred accumulate goes first)
     // the maps are updated in launch order: wait for whatever the other lane has enqueued so far
     // (its accumulate and shade), not for this lane's successor
     if (int rc = order_after_previous(c)) return rc;
     hipStream_t ls;
     if (int rc = lane_stream(c, &ls, true)) return rc;
+    if (tri_count == c->T && c->T > 0) {
+        // deferred: the ordering is enqueued, the launch waits for the next call -- a uvrt_shade takes it along in one
+        // kernel (uvrt_ctx.h PendingAcc), anything else launches it first
+        c->pend.valid = true;
+        c->pend.lane = c->lane;
+        c->pend.time_step = time_step;
+        c->counts_dirty[c->lane] = false;
+        return UVRT_OK;
+    }
     launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), lane_counts(c).as<int32_t>(),
                       c->replicas, c->T, time_step, tri_count, ls);
-    if (tri_count == c->T) c->counts_dirty[c->lane] = false;
     HIP_TRY(hipGetLastError());
     return UVRT_OK;
 }
@@ -398,6 +406,19 @@ int uvrt_shade(uvrt_ctx* c, int32_t which, int32_t photons_per_light, float scal
         return fail(UVRT_ERR_INVALID, "uvrt_shade: bad tri_count");
     if (which != UVRT_MAP_SUM && which != UVRT_MAP_MAX)
         return fail(UVRT_ERR_INVALID, "uvrt_shade: which_map must be 0 or 1");
+    if (c->pend.valid && c->pend.lane == c->lane && tri_count == c->T) {
+        // the launch's accumulate is still pending on this lane: accumulate + computeDosage + dosageToColor in one kernel
+        if (int rc = set_device_only(c)) return rc;
+        hipStream_t fs;
+        if (int rc = lane_stream(c, &fs, true)) return rc;
+        c->pend.valid = false;
+        launch_accumulate_shade(c->photon_map.as<double>(), c->max_map.as<double>(), lane_counts(c).as<int32_t>(), c->replicas,
+                                c->T, c->pend.time_step, c->dosage.as<float>(), c->area.as<float>(), c->color.as<float>(),
+                                which == UVRT_MAP_SUM ? 0 : 1, photons_per_light, scaled_power, min_value, threshold_view,
+                                tri_count, fs);
+        HIP_TRY(hipGetLastError());
+        return UVRT_OK;
+    }
     if (int rc = set_device(c)) return rc;
     const double* map = which == UVRT_MAP_SUM ? c->photon_map.as<double>() : c->max_map.as<double>();
     hipStream_t ls;

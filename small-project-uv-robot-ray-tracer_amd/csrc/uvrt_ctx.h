@@ -188,8 +188,15 @@ struct uvrt_ctx {
     size_t batch_chunk_bytes = (size_t)96 << 20;   // rays per fused launch of a batch (developer knob UVRT_BATCH_CHUNK_MB,
                                                    // read once in uvrt_create): a chunk's rays stay in the Infinity Cache
 
+    // A deferred accumulate (uvrt_accumulate stores it, its ordering already enqueued on the lane's stream): the Shade that
+    // the host loop runs right after a launch (myapp.cpp:159-160) takes it along in ONE kernel (k_accumulate_shade); every
+    // other entry point first launches it as the plain k_accumulate (set_device -> flush_pending).  Same arithmetic, same
+    // order of operations on the maps: the launch count of an iteration drops from 4 to 3.
+    struct PendingAcc { bool valid = false; int lane = 0; float time_step = 0; } pend;
     // traversal error flag + extend timing
-    DevBuf error_flag;
+    uint32_t* host_flag = nullptr;             // pinned, device-visible host word the kernels raise on a stack overflow: uvrt_sync
+    uint32_t* host_flag_dev = nullptr;         // reads it after the stream sync, no copy (its device-side address)
+    DevBuf error_flag;                         // (developer build with trip statistics: the flag and the counters behind it)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -198,14 +205,32 @@ struct uvrt_ctx {
 namespace uvrt_impl {
 using namespace uvrt;
 
-inline int set_device(uvrt_ctx* c)
+// ---- launch lanes ----
+inline hipStream_t stream_of(uvrt_ctx* c, int l) { return l == 0 ? c->stream : c->side[l]; }
+
+inline int set_device_only(uvrt_ctx* c)
 {
     HIP_TRY(hipSetDevice(c->device));
     return UVRT_OK;
 }
-
-// ---- launch lanes ----
-inline hipStream_t stream_of(uvrt_ctx* c, int l) { return l == 0 ? c->stream : c->side[l]; }
+// the deferred accumulate as a launch of its own, on the stream of the lane it belongs to (ordering enqueued by uvrt_accumulate)
+inline int flush_pending(uvrt_ctx* c)
+{
+    if (!c->pend.valid) return UVRT_OK;
+    c->pend.valid = false;
+    const int l = c->pend.lane;
+    launch_accumulate(c->photon_map.as<double>(), c->max_map.as<double>(), (l ? c->xcounts[l] : c->counts).as<int32_t>(),
+                      c->replicas, c->T, c->pend.time_step, c->T, stream_of(c, l));
+    HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+// every entry point that touches the device starts here (uvrt_shade, which may take a deferred accumulate along, uses
+// set_device_only)
+inline int set_device(uvrt_ctx* c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return flush_pending(c);
+}
 // the main stream becomes ordered after everything the side streams hold
 inline int join_all(uvrt_ctx* c)
 {

@@ -279,6 +279,10 @@ void launch_compute_dosage(const double* map, float* dosage, const float* area,
                            hipStream_t s);
 void launch_shade(const double* map, float* dosage, const float* area, float* color, int32_t photons_per_light,
                   float scaled_power, float min_value, int32_t threshold_view, int32_t T, hipStream_t s);
+void launch_accumulate_shade(double* photon_map, double* max_map, int32_t* counts, int32_t replicas, int64_t stride,
+                             float time_step, float* dosage, const float* area, float* color, int32_t which_map,
+                             int32_t photons_per_light, float scaled_power, float min_value, int32_t threshold_view,
+                             int32_t T, hipStream_t s);
 void launch_dosage_to_color(const float* dosage, float* color, float min_value,
                             int32_t threshold_view, int32_t T, hipStream_t s);
 void launch_prepare_scene(const float4* tris64, const uint32_t* tri_idx, LeafTri* ltris,

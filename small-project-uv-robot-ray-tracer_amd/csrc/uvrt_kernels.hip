@@ -346,16 +346,12 @@ __global__ __launch_bounds__(256) void k_dosage_to_color(const float* __restrict
     c[6] = r; c[7] = g; c[8] = b;
 }
 
-// computeDosage + dosageToColor in one pass (RayTracer::Shade always runs them back to back,
-// raytracer.cpp:93-120); same operations, the dose still goes through its f32 store
-__global__ __launch_bounds__(256) void k_shade(const double* __restrict__ map, float* __restrict__ dosage,
-                                               const float* __restrict__ area, float* __restrict__ color,
-                                               int32_t photons_per_light, float scaled_power,
-                                               float min_value, int32_t threshold_view, int32_t T)
+// computeDosage + dosageToColor of triangle i from its map value (shade.cl:23-71); the dose still goes through its f32 store
+__device__ __forceinline__ void shade_one(int i, double map_value, float* __restrict__ dosage, const float* __restrict__ area,
+                                          float* __restrict__ color, int32_t photons_per_light, float scaled_power,
+                                          float min_value, int32_t threshold_view)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T) return;
-    const double num = (double)scaled_power * map[i];                   // shade.cl:39
+    const double num = (double)scaled_power * map_value;                // shade.cl:39
     const float den = area[i] * (float)photons_per_light;
     const float dose = (float)(num / (double)den);
     dosage[i] = dose;
@@ -368,6 +364,49 @@ __global__ __launch_bounds__(256) void k_shade(const double* __restrict__ map, f
     c[0] = r; c[1] = g; c[2] = b;
     c[3] = r; c[4] = g; c[5] = b;
     c[6] = r; c[7] = g; c[8] = b;
+}
+
+// computeDosage + dosageToColor in one pass (RayTracer::Shade always runs them back to back,
+// raytracer.cpp:93-120); same operations
+__global__ __launch_bounds__(256) void k_shade(const double* __restrict__ map, float* __restrict__ dosage,
+                                               const float* __restrict__ area, float* __restrict__ color,
+                                               int32_t photons_per_light, float scaled_power,
+                                               float min_value, int32_t threshold_view, int32_t T)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    shade_one(i, map[i], dosage, area, color, photons_per_light, scaled_power, min_value, threshold_view);
+}
+
+// accumulate.cl:4-14 of the launch just traced and the Shade that the host loop runs right after it (myapp.cpp:159-160)
+// in ONE launch: k_accumulate's fold of the deposit replicas and its map update, then shade_one on the value just written.
+// which_map: 0 photonMap, 1 maxPhotonMap.
+__global__ __launch_bounds__(256) void k_accumulate_shade(double* __restrict__ photon_map, double* __restrict__ max_map,
+                                                          int32_t* __restrict__ counts, int32_t replicas, int64_t stride,
+                                                          float time_step, float* __restrict__ dosage,
+                                                          const float* __restrict__ area, float* __restrict__ color,
+                                                          int32_t which_map, int32_t photons_per_light, float scaled_power,
+                                                          float min_value, int32_t threshold_view, int32_t T)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int i = g >> 2, part = g & 3;
+    int32_t total = 0;
+    if (i < T) {
+        for (int r = part; r < replicas; r += 4) {
+            total += counts[r * stride + i];
+            counts[r * stride + i] = 0;
+        }
+    }
+    total += __builtin_amdgcn_mov_dpp(total, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    total += __builtin_amdgcn_mov_dpp(total, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    if (i >= T || part != 0) return;
+    const double c = (double)total;
+    const double sum = photon_map[i] + c * (double)time_step;          // accumulate.cl:9
+    photon_map[i] = sum;
+    const double m = max_map[i];
+    const double mx = m < c ? c : m;                                    // accumulate.cl:11
+    max_map[i] = mx;
+    shade_one(i, which_map ? mx : sum, dosage, area, color, photons_per_light, scaled_power, min_value, threshold_view);
 }
 
 // Test hook: the reference's 32-byte Ray records (cl/tools.cl:8-14) in gid order.
@@ -474,6 +513,17 @@ void launch_shade(const double* map, float* dosage, const float* area, float* co
     if (T <= 0) return;
     hipLaunchKernelGGL(k_shade, dim3(blocks_for(T, 256)), dim3(256), 0, s, map, dosage, area, color,
                        photons_per_light, scaled_power, min_value, threshold_view, T);
+}
+
+void launch_accumulate_shade(double* photon_map, double* max_map, int32_t* counts, int32_t replicas, int64_t stride,
+                             float time_step, float* dosage, const float* area, float* color, int32_t which_map,
+                             int32_t photons_per_light, float scaled_power, float min_value, int32_t threshold_view,
+                             int32_t T, hipStream_t s)
+{
+    if (T <= 0) return;
+    hipLaunchKernelGGL(k_accumulate_shade, dim3(blocks_for((int64_t)T * 4, 256)), dim3(256), 0, s, photon_map, max_map, counts,
+                       replicas, stride, time_step, dosage, area, color, which_map, photons_per_light, scaled_power, min_value,
+                       threshold_view, T);
 }
 
 void launch_dosage_to_color(const float* dosage, float* color, float min_value,

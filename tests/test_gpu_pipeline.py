@@ -248,3 +248,66 @@ def test_external_work_on_the_maps_is_ordered_after_all_lanes(pkg, orc, oscene, 
         assert np.array_equal(final, want)
     finally:
         c.close()
+
+
+def test_the_deferred_accumulate_that_a_shade_takes_along_changes_nothing(pkg, orc, oscene, oroute):
+    """A full-range uvrt_accumulate is enqueued with the NEXT call: a uvrt_shade right behind it (the host loop's order,
+    myapp.cpp:159-160) runs accumulate + computeDosage + dosageToColor in one kernel, anything else launches the accumulate first.
+    Maps, dose, colours and SEED equal the oracle's and the one-stream sequence's whatever comes between the two calls."""
+    lps = positions(orc, oscene, oroute)
+    n = 70001
+    length = oroute["lightLength"]
+    plan = [(0, 0), (1, 1), (1, 0), (2, 1), (0, 0), (0, 1)]           # (lamp, which map the Shade reads)
+
+    def run(between, pipeline=True):
+        c = pkg.capi.Ctx(0)
+        try:
+            c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+            c.set_pipeline(pipeline)
+            c.resize_rays(n)
+            c.reset(True)
+            c.seed = 99
+            out = []
+            for k, (li, which) in enumerate(plan):
+                c.generate(lps[li], length, 0, n)
+                c.extend(n)
+                counts = c.read_counts() if k == 2 else None                # a test hook between extend and accumulate
+                c.accumulate(10.0 + k)
+                if between == "sync":
+                    c.sync()
+                elif between == "read":
+                    c.read_photon_map(k & 1)
+                elif between == "dose only":
+                    c.compute_dosage(which, (k + 1) * n, 44.0)
+                elif between == "twice" and k == 3:
+                    c.shade(1 - which, 5, 1.0, 1.0, 0)                      # an extra Shade: the second one finds nothing pending
+                c.shade(which, (k + 1) * n, 44.0, 100.0, k & 1)
+                if k & 1:
+                    c.sync()
+                out.append((c.read_dosage(), c.read_color(), c.seed, counts))
+            out.append((c.read_photon_map(0), c.read_photon_map(1)))
+            return out
+        finally:
+            c.close()
+
+    ref = run(None, pipeline=False)
+    for between in (None, "sync", "read", "dose only", "twice"):
+        got = run(between)
+        for a, b in zip(ref[:-1], got[:-1]):
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), between
+            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), between
+            assert a[2] == b[2], between
+            assert (a[3] is None) or np.array_equal(a[3], b[3]), between
+        assert np.array_equal(ref[-1][0], got[-1][0]) and np.array_equal(ref[-1][1], got[-1][1]), between
+    # and against the oracle
+    pm, mm, temp = np.zeros(oscene.T), np.zeros(oscene.T), np.zeros(oscene.T, dtype=np.int32)
+    seed = 99
+    for k, (li, _) in enumerate(plan):
+        rays, seed = orc.generate(0, n, lps[li], length, seed)
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+        orc.accumulate(pm, mm, temp, 10.0 + k)
+    assert np.array_equal(ref[-1][0], pm) and np.array_equal(ref[-1][1], mm) and ref[-2][2] == seed
+    dose = orc.compute_dosage(mm, oscene.tris, 6 * n, np.float32(44.0))
+    assert np.array_equal(ref[-2][0].view(np.uint32), dose.view(np.uint32))
+    col = orc.dosage_to_color(dose, 100.0, True)
+    assert np.array_equal(ref[-2][1].view(np.uint32), col.view(np.uint32))
