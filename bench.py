@@ -218,22 +218,27 @@ class _Scene:
     pass
 
 
-def issue_model_utilisation(m, rays, seconds):
-    """Utilisation of each unit while `rays` rays are traced in `seconds` of wall time: the kernel's per-ray
-    instruction / lookup / byte counts (rocprofv3 PMC passes, deterministic per launch; tests/tools/issue_model.py)
-    priced with the issue rates calibrated on this GPU type (tests/tools/valu_calib.hip,
-    profiles/r02/r02_valu_calibration.txt).  Returns (utilisation per unit, [lower, upper] of the VALU figure)."""
-    k, pr, vc = m["constants"], m["per_ray"], m["valu_issue_cycles"]
-    simd_cycles = k["simds"] * k["clock_hz"] * seconds
-    cu_cycles = k["cus"] * k["clock_hz"] * seconds
+def issue_model_utilisation(m, rays, seconds, clock_hz=None):
+    """Utilisation of each unit while `rays` rays are traced in `seconds` of wall time: the kernel's per-ray counts
+    (profiles/extend_issue_model_*.json, made by tests/tools/stream_census.py: VALU issue cycles = trip counts x the static
+    cycles of the hand-written stream per kind of trip + the compiler-written rest from the PMC instruction count; scalar
+    instructions, L1 lookups, fabric bytes and deposit atomics from rocprofv3 PMC passes -- all deterministic per launch)
+    over the unit peaks: issue slots at `clock_hz`, the shader clock MEASURED during the run (uvrt_clock_probe_*; nominal if
+    None), L1 lookups and scattered atomics at their calibrated rates (tests/tools/fetch_calib.hip, atomic_calib.hip).
+    Returns (utilisation per unit, [lower, upper] of the VALU figure)."""
+    k, pr = m["constants"], m["per_ray"]
+    clock = clock_hz or k["clock_hz_nominal"]
+    simd_cycles = k["simds"] * clock * seconds
+    cu_cycles = k["cus"] * clock * seconds
     util = {
         "valu_issue": pr["valu_issue_cycles"] * rays / simd_cycles,
         "salu_issue": pr["salu_insts"] * rays / cu_cycles,
         "l1_lookup": pr["l1_lane_lookups"] * rays / (cu_cycles * k["l1_lookups_per_clk_per_cu"]),
+        "deposit_atomics": pr["deposit_atomics"] * rays / seconds / k["scattered_atomic_adds_per_s"],
         "hbm": pr["hbm_bytes"] * rays / seconds / k["hbm_peak_bytes_per_s"],
     }
-    scale = rays / m["rays_per_launch"]
-    return util, [vc["lower"] * scale / simd_cycles, vc["upper"] * scale / simd_cycles]
+    lo, hi = pr["valu_issue_cycles_bracket"]
+    return util, [lo * rays / simd_cycles, hi * rays / simd_cycles]
 
 
 class Watchdog:
@@ -618,6 +623,7 @@ def main():
     weak = strong = None
     single_ms = None
     ext_ms = ext_launches = None
+    clock_mhz = None
     cold = route_leg = None
     timing_steps = max(1, min(3, args.steps))
     few = max(1, min(5, args.steps))
@@ -754,6 +760,19 @@ def main():
         rt.ctx.set_timing(False)
         rt.ctx.set_pipeline(not args.no_pipeline)
         rt.Sync()
+        # the shader clock UNDER THIS LOAD: a one-wave probe (s_memtime against the constant 100 MHz s_memrealtime) on a stream of
+        # its own while the headline steps run again exactly as they were timed; the clock moves between 2.0 and 2.4 GHz with the
+        # power the kernel draws, and the issue-rate peaks of the roofline move with it
+        clock_steps = max(2, min(10, args.steps))
+        span_us = int(0.8 * clock_steps * elapsed / args.steps * 1e6)
+        if span_us >= 1:
+            for _ in range(2):
+                headline()
+            rt.ctx.clock_probe_start(min(span_us, 1000000))
+            for _ in range(clock_steps):
+                headline()
+            sync_all()
+            clock_mhz = rt.ctx.clock_probe_read()
     else:
         # strong: BASELINE configs[3]
         rt.SetRayRange(rank, world)
@@ -830,9 +849,8 @@ def main():
             avg_ms = ext_ms / max(ext_launches, 1)
             rays_per_extend = rays_per_step * timing_steps / max(ext_launches, 1)
             model_mode = "batched" if args.mode == "batched" else "loop"
-            model_path = os.path.join(ROOT, "profiles", "extend_issue_model_%s.json" % model_mode)
-            if not os.path.exists(model_path):
-                model_path = os.path.join(ROOT, "profiles", "extend_issue_model.json")
+            model_path = os.path.join(ROOT, "profiles", "extend_issue_model_%s%s.json"
+                                      % (model_mode, "_flavour%d" % args.flavour if args.flavour else ""))
             step_sec = elapsed / args.steps
             if os.path.exists(model_path) and args.scene is None and not args.wide and not args.route:
                 # The binding resource at the level the driver times: the whole step.  Per-ray counts x the step's rays
@@ -841,13 +859,19 @@ def main():
                 m = json.load(open(model_path))
                 k = m["constants"]
                 pr = m["per_ray"]
-                util_step, bracket_step = issue_model_utilisation(m, rays_per_step, step_sec)
-                util_launch, bracket_launch = issue_model_utilisation(m, rays_per_extend, avg_ms * 1e-3)
-                roof = {"bound": "valu_issue", "kernel": kernel_name, "level": "step (driver-timed ms_per_step)",
+                clock_hz = clock_mhz * 1e6 if clock_mhz else None
+                util_step, bracket_step = issue_model_utilisation(m, rays_per_step, step_sec, clock_hz)
+                util_launch, bracket_launch = issue_model_utilisation(m, rays_per_extend, avg_ms * 1e-3, clock_hz)
+                busiest = max(util_step, key=util_step.get)
+                roof = {"bound": busiest, "kernel": kernel_name, "level": "step (driver-timed ms_per_step)",
                         "achieved": round(pr["valu_issue_cycles"] * rays_per_step / step_sec / 1e9, 1),
-                        "peak": round(k["simds"] * k["clock_hz"] / 1e9, 1), "unit": "G VALU issue-cycles/s",
+                        "peak": round(k["simds"] * (clock_hz or k["clock_hz_nominal"]) / 1e9, 1), "unit": "G VALU issue-cycles/s",
                         "frac": round(util_step["valu_issue"], 4),
                         "frac_bracket": [round(bracket_step[0], 4), round(bracket_step[1], 4)],
+                        "clock_measured_mhz": round(clock_mhz, 1) if clock_mhz else None,
+                        "clock_is": ("shader clock during %d of the timed kind of step (uvrt_clock_probe: s_memtime against the 100 MHz "
+                                     "s_memrealtime, one wave on its own stream)" % clock_steps) if clock_mhz else "nominal (no probe)",
+                        "frac_at_nominal_2400mhz": round(issue_model_utilisation(m, rays_per_step, step_sec, None)[0]["valu_issue"], 4),
                         "lane_utilisation": round(m["lane_utilisation"], 4),
                         "useful_lane_frac": round(util_step["valu_issue"] * m["lane_utilisation"], 4),
                         "step_level": {u: round(v, 4) for u, v in util_step.items()},
@@ -861,12 +885,15 @@ def main():
                                        "caveat": "in batched / pipelined modes two launches are co-resident: a launch's wall time "
                                                  "is not machine time, so these understate the units' load; step_level is the figure"},
                         "wave_time_waiting_on_memory": round(m["wave_wait_frac"], 3) if m.get("wave_wait_frac") else None,
-                        "clock_assumed_ghz": k["clock_hz"] / 1e9,
                         "timing_pass": "%d step(s) after the timed region; HIP events around the extend launch on its stream" % timing_steps,
                         "model": "%s (%s)" % (os.path.relpath(model_path, ROOT), m.get("note", "")),
-                        "note": "per-ray counts (PMC) x rays per step / (ms_per_step x unit peak), rates calibrated on the box; VALU "
-                                "issue is the busiest unit, HBM carries a few per cent (the 5.7 MB record set lives in L2 / LDS); "
-                                "packed f32 saves instructions, not issue cycles (DESIGN.md 4a)"}
+                        "valu_cycles_are": "per ray: stream trips x static cycles per kind of trip (%.0f %% of the VALU instructions, exact) + the "
+                                           "compiler-written rest at its static mean cost +- 15 %% (tests/tools/stream_census.py)"
+                                           % (100.0 * m["stream_share_of_valu_insts"]),
+                        "note": "per-ray counts x rays per step / (ms_per_step x unit peak); issue peaks at the MEASURED shader clock; "
+                                "deposit_atomics = scattered int32 atomic adds against the calibrated 27 G/s (every deposit leaves L2); HBM "
+                                "carries a few per cent (the 5.7 MB record set lives in L2 / LDS); packed f32 saves instructions, not issue "
+                                "cycles (DESIGN.md 4a)"}
             if census is not None and not args.route:
                 # SURVEY.md 8d's HBM-read figure (algorithmic bytes of the REFERENCE's layout, every node visit
                 # priced as a memory read): secondary on the L2-resident room, primary on a scene beyond L2

@@ -269,6 +269,12 @@ int uvrt_copy_device(uvrt_ctx* ctx, int32_t which, void* ext_dev_ptr, int32_t to
  * context's stream), and the number of extend launches; synchronises. */
 int uvrt_extend_time_ms(uvrt_ctx* ctx, double* ms, int64_t* launches);
 int uvrt_set_timing(uvrt_ctx* ctx, int32_t on);
+/* measurement hook: the shader clock UNDER LOAD.  _start enqueues a one-wave kernel on a stream of its own that reads the
+ * shader-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) `microseconds` apart, beside whatever the
+ * context's streams are doing; _read waits for it and returns ticks ratio x 100 MHz.  bench.py prices the issue-rate peaks of its
+ * roofline with the clock measured during its own steps instead of the nominal 2.4 GHz. */
+int uvrt_clock_probe_start(uvrt_ctx* ctx, int32_t microseconds);
+int uvrt_clock_probe_read(uvrt_ctx* ctx, double* shader_mhz);
 /* compute units of the context's device (the persistent extend grid is 8 workgroups per CU) */
 int uvrt_device_cus(uvrt_ctx* ctx);
 /* HIP devices visible to the process (0 when there is none) */

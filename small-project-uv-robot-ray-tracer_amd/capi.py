@@ -77,6 +77,8 @@ SYMBOLS = [
     ("uvrt_copy_device", C.c_int, [_vp, _i32, _vp, _i32]),
     ("uvrt_extend_time_ms", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     ("uvrt_set_timing", C.c_int, [_vp, _i32]),
+    ("uvrt_clock_probe_start", C.c_int, [_vp, _i32]),
+    ("uvrt_clock_probe_read", C.c_int, [_vp, C.POINTER(C.c_double)]),
     ("uvrt_device_cus", C.c_int, [_vp]),
     ("uvrt_device_count", C.c_int, []),
 ]
@@ -357,6 +359,14 @@ class Ctx:
 
     def copy_device(self, which, ext_ptr, to_ctx):
         self._ck(self._L.uvrt_copy_device(self._h, int(which), C.c_void_p(int(ext_ptr)), int(bool(to_ctx))))
+
+    def clock_probe_start(self, microseconds):
+        self._ck(self._L.uvrt_clock_probe_start(self._h, int(microseconds)))
+
+    def clock_probe_read(self):
+        mhz = C.c_double()
+        self._ck(self._L.uvrt_clock_probe_read(self._h, C.byref(mhz)))
+        return float(mhz.value)
 
     def device_cus(self):
         return int(self._L.uvrt_device_cus(self._h))

@@ -26,6 +26,33 @@ extern "C" {
 
 const char* uvrt_last_error(void) { return g_err.c_str(); }
 const char* uvrt_version(void) { return "uvrt-mi355x 0.1 (gfx950)"; }
+int uvrt_clock_probe_start(uvrt_ctx* c, int32_t microseconds)
+{
+    if (!c || microseconds < 1 || microseconds > 1000000) return fail(UVRT_ERR_INVALID, "uvrt_clock_probe_start: 1 .. 1 000 000 us");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->probe_stream) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->probe_stream, hipStreamNonBlocking, hi));     // a wave slot as soon as one frees
+    }
+    if (int rc = c->probe_out.ensure(16, true, c->probe_stream)) return rc;
+    launch_clock_probe(c->probe_out.as<unsigned long long>(), (unsigned long long)microseconds * 100ull, c->probe_stream);
+    HIP_TRY(hipGetLastError());
+    return UVRT_OK;
+}
+
+int uvrt_clock_probe_read(uvrt_ctx* c, double* shader_mhz)
+{
+    if (!c || !shader_mhz || !c->probe_stream) return fail(UVRT_ERR_INVALID, "uvrt_clock_probe_read: no probe started");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(v, c->probe_out.p, 16, hipMemcpyDeviceToHost, c->probe_stream));
+    HIP_TRY(hipStreamSynchronize(c->probe_stream));
+    if (v[1] == 0) return fail(UVRT_ERR_HIP, "uvrt_clock_probe_read: the probe wrote nothing");
+    *shader_mhz = (double)v[0] / (double)v[1] * 100.0;          // s_memrealtime ticks at 100 MHz
+    return UVRT_OK;
+}
+
 int uvrt_device_cus(uvrt_ctx* c) { return c ? c->num_cus : 0; }
 int uvrt_device_count(void)
 {
@@ -131,6 +158,8 @@ void uvrt_destroy(uvrt_ctx* c)
         b->release();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->host_flag) (void)hipHostFree(c->host_flag);
+    if (c->probe_stream) { (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
+    c->probe_out.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -474,7 +503,7 @@ int uvrt_sync(uvrt_ctx* c)
 #endif
 #ifdef UVRT_TRIP_STATS
     if (getenv("UVRT_TRIP_STATS")) {
-        unsigned long long st[21];
+        unsigned long long st[27];
         HIP_TRY(hipMemcpy(st, (char*)c->error_flag.p + 8, sizeof st, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset((char*)c->error_flag.p + 8, 0, sizeof st));
         if (st[1]) {
@@ -490,6 +519,9 @@ int uvrt_sync(uvrt_ctx* c)
                     st[19] / w, st[15] / w, st[16] / w, st[17] / w, st[18] / w, st[20] / w,
                     (st[19] - st[15] - st[16] - st[17] - st[18] - st[20]) / w,
                     st[15] / t, st[16] / t, st[17] / t, (double)st[18] / (double)(st[9] ? st[9] : 1), (double)st[20] / (double)(st[8] ? st[8] : 1));
+            // totals since the last sync, for tests/tools/stream_census.py
+            fprintf(stderr, "trip census: waves %llu stream_in %llu stream_leaf %llu stream_both %llu general_exact %llu general_other %llu "
+                    "refills %llu leaf_lane_tests %llu trips %llu\n", st[0], st[21], st[22], st[23], st[24], st[25], st[9], st[26], st[1]);
         }
     }
 #endif

@@ -197,6 +197,8 @@ struct uvrt_ctx {
     uint32_t* host_flag = nullptr;             // pinned, device-visible host word the kernels raise on a stack overflow: uvrt_sync
     uint32_t* host_flag_dev = nullptr;         // reads it after the stream sync, no copy (its device-side address)
     DevBuf error_flag;                         // (developer build with trip statistics: the flag and the counters behind it)
+    hipStream_t probe_stream = nullptr;        // uvrt_clock_probe_start's own stream (created on first use)
+    DevBuf probe_out;                          // {shader ticks, 100 MHz ticks}
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;

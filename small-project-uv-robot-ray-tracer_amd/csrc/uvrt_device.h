@@ -287,6 +287,7 @@ void launch_dosage_to_color(const float* dosage, float* color, float min_value,
                             int32_t threshold_view, int32_t T, hipStream_t s);
 void launch_prepare_scene(const float4* tris64, const uint32_t* tri_idx, LeafTri* ltris,
                           float* area, int32_t T, hipStream_t s);
+void launch_clock_probe(unsigned long long* out2, unsigned long long ticks_100mhz, hipStream_t s);
 void launch_export_rays(const float4* rays, const uint2* hits, void* out32, float ox, float oz,
                         int64_t first, int64_t count, hipStream_t s);
 

@@ -584,6 +584,10 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 #ifdef UVRT_TRIP_STATS     // developer build (tests/tools/trip_stats.sh): where the trips' lanes go
     uint32_t st_trips = 0, st_in = 0, st_leaf = 0, st_wait = 0, st_idle = 0, st_leaftrips = 0, st_drain = 0, st_slow = 0,
              st_refills = 0, st_top = 0, st_d9 = 0, st_d10 = 0, st_d11 = 0, st_d12 = 0;
+    // the trips by the kind of work the product's instruction stream (run7) does for them -- the census that prices the kernel's
+    // VALU issue cycles (tests/tools/stream_census.py): stream trips with / without the box block and with / without the
+    // triangle block, trips the stream hands to the general step (by its arithmetic form), stream exits
+    uint32_t st_s_in = 0, st_s_leaf = 0, st_s_both = 0, st_g_exact = 0, st_g_other = 0, st_tris = 0;
     uint32_t clk4 = 0;                // cycles in the general step
     uint32_t clk[4] = {0, 0, 0, 0};   // cycles in: record fetch (issue to data), leaf tests, box tests + descend, refill
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -756,6 +760,20 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
         st_d11 += __builtin_amdgcn_ballot_w64(L.sp >= 11) != 0; st_d12 += __builtin_amdgcn_ballot_w64(L.sp >= 12) != 0;
 #endif
 #endif
+#ifdef UVRT_TRIP_STATS
+        {
+            // run7 leaves to the general step for special lanes, stacks beyond LDS, and leaf trips that visit a leaf with several
+            // triangles; everything else is a stream trip
+            const unsigned long long m_vis = m_lf & kme;
+            const bool multi = __builtin_amdgcn_ballot_w64(((m_vis >> (threadIdx.x & 63)) & 1ull) && ((L.cur >> REF_COUNT_SHIFT) & 15u) != 1u) != 0;
+            if ((special_mask | m_deep) != 0 || multi) {
+                if ((special_mask & (m_in | m_lf)) != 0) ++st_g_exact; else ++st_g_other;
+            } else {
+                if (m_in != 0 && m_vis != 0) ++st_s_both; else if (m_in != 0) ++st_s_in; else ++st_s_leaf;
+            }
+            st_tris += (uint32_t)__popcll(m_vis);
+        }
+#endif
         if ((special_mask | m_deep) != 0) {
 #ifdef UVRT_TRIP_STATS
             const unsigned long long t0_ = __builtin_readcyclecounter();
@@ -775,10 +793,11 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 #ifdef UVRT_TRIP_STATS
     if ((threadIdx.x & 63) == 0) {
         unsigned long long* st = (unsigned long long*)(p.error_flag + 2);
-        const uint32_t v[20] = {st_trips, st_in, st_leaf, st_wait, st_idle, st_leaftrips, st_drain, st_slow, st_refills, st_top,
+        const uint32_t v[26] = {st_trips, st_in, st_leaf, st_wait, st_idle, st_leaftrips, st_drain, st_slow, st_refills, st_top,
                                 st_d9, st_d10, st_d11, st_d12, clk[0], clk[1], clk[2], clk[3],
-                                (uint32_t)(__builtin_readcyclecounter() - t_begin), clk4};
-        for (int i = 0; i < 20; ++i) atomicAdd(&st[i + 1], (unsigned long long)v[i]);
+                                (uint32_t)(__builtin_readcyclecounter() - t_begin), clk4,
+                                st_s_in, st_s_leaf, st_s_both, st_g_exact, st_g_other, st_tris};
+        for (int i = 0; i < 26; ++i) atomicAdd(&st[i + 1], (unsigned long long)v[i]);
         atomicAdd(&st[0], 1ull);
     }
 #endif

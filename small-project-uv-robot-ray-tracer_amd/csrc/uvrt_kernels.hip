@@ -409,6 +409,29 @@ __global__ __launch_bounds__(256) void k_accumulate_shade(double* __restrict__ p
     shade_one(i, which_map ? mx : sum, dosage, area, color, photons_per_light, scaled_power, min_value, threshold_view);
 }
 
+// Measurement hook (uvrt_clock_probe_start): one wave reads the shader-clock counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime) `ticks` of the latter apart, sleeping in between; out = {shader ticks, 100 MHz ticks}.  Launched on a stream of
+// its own beside whatever the device is doing, it tells what the shader clock IS under that load (the issue-rate peaks of the
+// bench line's roofline scale with it; it moves between 2.0 and 2.4 GHz with the power the load draws).
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, unsigned long long ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
+void launch_clock_probe(unsigned long long* out, unsigned long long ticks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, out, ticks);
+}
+
 // Test hook: the reference's 32-byte Ray records (cl/tools.cl:8-14) in gid order.
 __global__ __launch_bounds__(256) void k_export_rays(const float4* __restrict__ rays,
                                                      const uint2* __restrict__ hits,
