@@ -201,7 +201,7 @@ int uvrt_set_record_hits(uvrt_ctx* ctx, int32_t on);
  *     f = v_rcp_f32(a) (extend.cl:17).  (dist bits, triID, counts) equal that kernel's bit for bit; against
  *     flavours 0 / 1 a few rays per million land on a neighbouring triangle (the dose stays within 1e-4).  v_rcp_f32
  *     is specific to the GPU generation: a CPU restatement reproduces this flavour only with the instruction's table
- *     read from the device.  Not available with the opt-in 4-wide walk.  Rays whose direction
+ *     read from the device.  Rays whose direction
  *     has all three components zero or NaN are outside this flavour's parity domain. */
 int uvrt_set_flavour(uvrt_ctx* ctx, int32_t flavour);
 /* OPT-IN 4-wide traversal: uvrt_extend walks a one-level collapse of the caller's BVH

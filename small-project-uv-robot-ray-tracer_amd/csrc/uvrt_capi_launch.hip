@@ -300,8 +300,6 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
         ++c->ev_used;
         HIP_TRY(hipEventRecord(e0, ls));
     }
-    if (c->wide && c->nquads > 0 && c->flavour == 2)
-        return fail(UVRT_ERR_INVALID, "uvrt_extend: the opt-in 4-wide walk has no \"shipped flags\" arithmetic (uvrt_set_flavour 2)");
     if (c->wide && c->nquads > 0) {
         // the opt-in 4-wide walk: its per-launch records are (re)made here when the lane's are for another lamp
         DevBuf& r4 = c->recs4[c->lane];

@@ -23,7 +23,7 @@ constexpr uint32_t TOP4_MAX = 64;         // nodes cached in LDS
 constexpr uint32_t TOP4_STRIDE = 144;     // bytes per cached node (128 + 16 padding): 9 KB
 constexpr uint32_t KEY_MISS = 0xFFFFFFFFu;
 
-template <bool OCL>
+template <int FL>
 __device__ __forceinline__ void step4(Lane6& L, const ExtendParams& p, uint32_t stack_base, const float4* s_top,
                                       uint32_t top_units, bool leaf_trip, bool exact, unsigned long long m_act)
 {
@@ -79,11 +79,11 @@ __device__ __forceinline__ void step4(Lane6& L, const ExtendParams& p, uint32_t 
         const uint32_t first = idx - 2u * (uint32_t)p.nquads;
         if (count == 15u) count = p.scene.leaf_count[first];
         float dist = L.po.y;
-        tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, make_float4(w0.x, w0.y, w0.z, w0.w),
+        tri6<FL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, make_float4(w0.x, w0.y, w0.z, w0.w),
                   make_float4(w1.x, w1.y, w1.z, w1.w), make_float4(w2.x, w2.y, w2.z, w2.w), exact);
         for (uint32_t i = 1; i < count; ++i) {
             const float4* lt = (const float4*)p.recs4 + ((size_t)idx + i) * 4;
-            tri6<OCL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
+            tri6<FL>(p.ox, L.po.x, p.oz, L.px.x, L.py.x, L.pz.x, dist, L.triID, lt[0], lt[1], lt[2], exact);
         }
         L.po.y = dist;
     }
@@ -95,7 +95,11 @@ __device__ __forceinline__ void step4(Lane6& L, const ExtendParams& p, uint32_t 
                            __builtin_shufflevector(w5, w5, 0, 1), __builtin_shufflevector(w5, w5, 2, 3)};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (exact) {
+            if (FL == 2) {       // "shipped flags": t = (b - o) * v_rcp_f32(d) (uvrt_traverse.h slabs6s)
+                v2f x = __builtin_shufflevector(xz[k], xz[k], 0, 1), z = __builtin_shufflevector(xz[k], xz[k], 2, 3), y = yy[k];
+                slabs6s(x, y, z, L.px, L.py, L.pz, L.po);
+                h[k] = box_fast(x, y, z, L.po.y, d[k]);
+            } else if (exact) {
                 h[k] = box_exact(xz[k].x, xz[k].y, yy[k].x - L.po.x, yy[k].y - L.po.x, xz[k].z, xz[k].w, L.px.x, L.py.x,
                                  L.pz.x, L.po.y, d[k]);
             } else {
@@ -136,7 +140,7 @@ __device__ __forceinline__ void step4(Lane6& L, const ExtendParams& p, uint32_t 
     }
 }
 
-template <bool RECORD, bool OCL>
+template <bool RECORD, int FL>
 __global__ __launch_bounds__(256, 6) void k_extend4(ExtendParams p)
 {
     __shared__ uint32_t s_stack[PS6][256];                              // 8 KB
@@ -192,9 +196,9 @@ __global__ __launch_bounds__(256, 6) void k_extend4(ExtendParams p)
                 if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
                     set_in_place(plane_off, pl * p.plane_stride);
                     const float4 rec = p.rays[my];
-                    set_in_place(L.px, rec.x, rcp_exact(rec.x));
-                    set_in_place(L.py, rec.y, rcp_exact(rec.y));
-                    set_in_place(L.pz, rec.z, rcp_exact(rec.z));
+                    set_in_place(L.px, rec.x, FL == 2 ? rcp_raw(rec.x) : rcp_exact(rec.x));
+                    set_in_place(L.py, rec.y, FL == 2 ? rcp_raw(rec.y) : rcp_exact(rec.y));
+                    set_in_place(L.pz, rec.z, FL == 2 ? rcp_raw(rec.z) : rcp_exact(rec.z));
                     set_in_place(L.po, rec.w, 1e30f);
                     set_in_place(L.triID, 0u);
                     if (RECORD) { slot = my; live = true; }
@@ -202,9 +206,9 @@ __global__ __launch_bounds__(256, 6) void k_extend4(ExtendParams p)
                     set_in_place(L.cur, p.root_ref4);
                     const float ay = fabsf(rec.w), adx = fabsf(rec.x), ady = fabsf(rec.y), adz = fabsf(rec.z);
                     const float dmin = 8.6736174e-19f;
-                    spec = !(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
+                    spec = FL != 2 && (!(adx >= dmin) || !(ady >= dmin) || !(adz >= dmin) ||
                            !(adx <= 1.0f) || !(ady <= 1.0f) || !(adz <= 1.0f) ||
-                           (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0;
+                           (ay != 0.0f && ay < 7.888609e-31f) || !(ay <= 1e9f) || p.force_exact != 0);
                 }
             }
             cursor += (uint32_t)nidle;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256, 6) void k_extend4(ExtendParams p)
         }
         const bool leaf_trip = (trip & 1u) == 0u || __builtin_amdgcn_ballot_w64(L.cur < REF_LEAF_BIT) == 0;
         ++trip;
-        step4<OCL>(L, p, stack_base, s_top, 2u * top_quads, leaf_trip, (special_mask & act) != 0, act);
+        step4<FL>(L, p, stack_base, s_top, 2u * top_quads, leaf_trip, (special_mask & act) != 0, act);
     }
     if (RECORD && live && p.hits) {
         const uint32_t li = p.order ? p.order[slot] : slot;
@@ -267,12 +271,15 @@ bool launch_extend4(const ExtendParams& p0, int grid_per_cu, hipStream_t s)
     if ((uint64_t)grid * 256 * (MAXS6 - PS6) > p.ovf_capacity) return false;
     p.root_ref4 = (p.scene.root_ref >= REF_LEAF_BIT && p.scene.root_ref != REF_DONE)
                       ? p.scene.root_ref + 2u * (uint32_t)p.nquads : p.scene.root_ref;
-    if (p.flavour) {
-        if (p.hits) hipLaunchKernelGGL((k_extend4<true, true>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_extend4<false, true>), dim3(grid), dim3(256), 0, s, p);
+    if (p.flavour == 2) {
+        if (p.hits) hipLaunchKernelGGL((k_extend4<true, 2>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_extend4<false, 2>), dim3(grid), dim3(256), 0, s, p);
+    } else if (p.flavour) {
+        if (p.hits) hipLaunchKernelGGL((k_extend4<true, 1>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_extend4<false, 1>), dim3(grid), dim3(256), 0, s, p);
     } else {
-        if (p.hits) hipLaunchKernelGGL((k_extend4<true, false>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_extend4<false, false>), dim3(grid), dim3(256), 0, s, p);
+        if (p.hits) hipLaunchKernelGGL((k_extend4<true, 0>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_extend4<false, 0>), dim3(grid), dim3(256), 0, s, p);
     }
     return true;
 }

@@ -151,7 +151,10 @@ def test_flavour2_whole_computation_through_every_tracing_path(ref, table, pkg, 
     assert far <= 40
 
 
-def test_flavour2_is_refused_where_it_does_not_exist(pkg, orc, oscene, oroute):
+def test_flavour_range_and_the_wide_walk_in_flavour2(ref, table, pkg, orc, oscene, oroute):
+    """uvrt_set_flavour accepts 0, 1, 2; the opt-in 4-wide walk (uvrt_set_wide_bvh) carries the shipped-flags arithmetic too:
+    its counts equal the oracle's in flavour 2 on this scene (the wide walk's own caveat -- order-dependent exact ties -- stands)."""
+    n = 500000
     c = pkg.capi.Ctx(0)
     try:
         c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
@@ -159,12 +162,24 @@ def test_flavour2_is_refused_where_it_does_not_exist(pkg, orc, oscene, oroute):
             c.set_flavour(3)
         c.set_flavour(2)
         c.set_wide_bvh(True)
-        c.resize_rays(4096)
-        c.generate(lamp(orc, oscene, oroute, 0), 1.0, 0, 4096)
-        with pytest.raises(pkg.capi.UvrtError, match="4-wide"):
-            c.extend(4096)
+        c.resize_rays(n)
+        lp = lamp(orc, oscene, oroute, 3)
+        c.reset(False)
+        c.seed = 11
+        c.generate(lp, oroute["lightLength"], 0, n)
+        c.extend(n)
+        c.sync()
+        got = c.read_counts()
     finally:
         c.close()
+    rays, _ = orc.generate(0, n, lp, oroute["lightLength"], 11)
+    temp = np.zeros(oscene.T, dtype=np.int32)
+    orc.set_flavour(2)
+    try:
+        orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+    finally:
+        orc.set_flavour(0)
+    assert np.array_equal(got, temp)
 
 
 def test_reference_generate_built_with_its_own_flags(ref, orc, oscene, oroute):

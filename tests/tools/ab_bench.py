@@ -27,7 +27,9 @@ variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
 # FLAVOURS=0,2: every variant in each of these arithmetic flavours (uvrt_set_flavour), interleaved like the variants; a
 # cell is then named 10000 * flavour + variant.  The dose CRC must agree within a flavour.
 flavours = [int(v) for v in os.environ.get("FLAVOURS", os.environ.get("FLAVOUR", "0")).split(",")]
-cells = [(f, v) for f in flavours for v in variants]
+# WIDES=0,1: the default BVH2 walk / the opt-in 4-wide walk (uvrt_set_wide_bvh; loop modes only -- batches use the default walk)
+wides = [int(v) for v in os.environ.get("WIDES", os.environ.get("WIDE", "0")).split(",")]
+cells = [(f, v, w) for f in flavours for v in variants for w in wides]
 mode = os.environ.get("MODE", "batched")
 steps = int(os.environ.get("STEPS", "20"))
 rounds = int(os.environ.get("ROUNDS", "5"))
@@ -48,8 +50,6 @@ else:
 rt.set_lamps(rt.lamps()[:nlamps])
 rt.photonCount = photons * nlamps
 rt.maxIterations = waves
-if os.environ.get("WIDE", "0") == "1":
-    rt.ctx.set_wide_bvh(True)
 rays_per_step = waves * rt.photonsPerLight * nlamps
 
 
@@ -72,9 +72,10 @@ crcs = {}
 iso = {}
 for rnd in range(rounds + 1):                 # round 0 = warm-up (allocations, hot records, clocks)
     for c in cells:
-        f, v = c
+        f, v, w = c
         rt.ctx.set_flavour(f)
         rt.ctx.set_variant(v)
+        rt.ctx.set_wide_bvh(bool(w))
         step()
         rt.Sync()
         t0 = time.perf_counter()
@@ -89,9 +90,10 @@ if os.environ.get("ISOLATED", "0") == "1":
     rt.ctx.set_pipeline(False)
     for rnd in range(3):
         for c in cells:
-            f, v = c
+            f, v, w = c
             rt.ctx.set_flavour(f)
             rt.ctx.set_variant(v)
+            rt.ctx.set_wide_bvh(bool(w))
             rt.ctx.set_timing(True)
             rt.ctx.extend_time_ms()
             rt.ctx.seed = 0
@@ -106,8 +108,8 @@ if os.environ.get("ISOLATED", "0") == "1":
 base = np.median(res[cells[0]])
 for c in cells:
     a = np.array(res[c])
-    line = "variant %5d flavour %d  %s  median %8.1f  best %8.1f  min %8.1f Mray/s  (%+.2f %% vs the first)  crc %s" % (
-        c[1], c[0], mode, np.median(a), a.max(), a.min(), 100.0 * (np.median(a) / base - 1.0), crcs[c])
+    line = "variant %5d flavour %d wide %d  %s  median %8.1f  best %8.1f  min %8.1f Mray/s  (%+.2f %% vs the first)  crc %s" % (
+        c[1], c[0], c[2], mode, np.median(a), a.max(), a.min(), 100.0 * (np.median(a) / base - 1.0), crcs[c])
     if c in iso:
         line += "  isolated extend %.4f ms" % min(iso[c])
     print(line, flush=True)
