@@ -436,6 +436,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "4:\n\t" \
         "s_cmp_eq_u64 %[m0], 0\n\t" \
         "s_cbranch_scc1 5f\n\t" \
+        "s_mov_b64 exec, %[m0]\n\t"   /* the box arithmetic under the inner lanes' mask: same issue cost, less switching power */ \
         SLABS \
         "v_min_f32 v58, v40, v41\n\t" \
         "v_min_f32 v59, v48, v49\n\t" \
@@ -453,7 +454,6 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "v_max_f32 v59, v50, v51\n\t" \
         "v_max_f32 v60, v46, v47\n\t" \
         "v_min3_f32 v54, v58, v59, v60\n\t" \
-        "s_mov_b64 exec, %[m0]\n\t" \
         "v_cmpx_ge_f32_e64 %[m2], v62, v61\n\t" \
         "v_cmpx_lt_f32_e64 %[m2], v61, %[dist]\n\t" \
         "v_cmpx_gt_f32_e64 %[m2], v62, 0\n\t" \
