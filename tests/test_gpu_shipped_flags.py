@@ -182,6 +182,65 @@ def test_flavour_range_and_the_wide_walk_in_flavour2(ref, table, pkg, orc, oscen
     assert np.array_equal(got, temp)
 
 
+def test_flavour2_on_hand_made_rays_equals_the_reference_kernel(ref, table, pkg, orc, oscene):
+    """Rays random photons reach once per ten million: exact zeros in the direction (v_rcp_f32 gives inf, (b - o) * inf is +-inf
+    or NaN where the origin lies on the slab plane and the hardware's min / max drop the NaN), origins on box planes, |d| > 1,
+    subnormal components (v_rcp_f32 flushes them: inf).  Flavour 2 has ONE form for all of them -- the instructions the
+    reference's own-flags build executes -- so product, oracle model and that kernel must still agree bit for bit."""
+    from test_gpu_adversarial import make_rays
+    nodes = oscene.nodes
+    inner = nodes[nodes["triCount"] == 0]
+    ox, oz = float(inner["minx"][3]), float(inner["maxz"][7])
+    rng = np.random.default_rng(3)
+    planes_y = np.concatenate([inner["miny"][:200], inner["maxy"][:200]])
+    dirs, oys = [], []
+    axes = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    for k in range(256 * 24):
+        kind = k % 8
+        if kind == 0:
+            d = axes[rng.integers(6)]
+        elif kind in (1, 2):
+            a = rng.normal(size=3); a[rng.integers(3)] = 0.0 if kind == 1 else -0.0; d = a / np.linalg.norm(a)
+        elif kind == 3:
+            a = rng.normal(size=3); d = 3.5 * a / np.linalg.norm(a)                      # not unit length
+        elif kind == 4:
+            a = rng.normal(size=3); d = a / np.linalg.norm(a); d[rng.integers(3)] = 1e-41   # subnormal component
+        elif kind == 5:
+            a = rng.normal(size=3); d = a / np.linalg.norm(a); d[rng.integers(3)] = -1e-30
+        else:
+            a = rng.normal(size=3); d = a / np.linalg.norm(a)
+        dirs.append(d)
+        oys.append(planes_y[rng.integers(planes_y.size)] if k % 2 else rng.uniform(-1.4, 1.3))
+    rays = make_rays(dirs, (ox, oz), oys)
+    r_rays = rays.copy()
+    r_counts, _ = orc.refgpu_extend(r_rays, oscene.tris, oscene.nodes, oscene.triIdx, shipped=True)
+    o_rays = rays.copy()
+    o_counts = np.zeros(oscene.T, dtype=np.int32)
+    orc.set_flavour(2)
+    try:
+        orc.extend(o_counts, oscene.tris, o_rays, oscene.nodes, oscene.triIdx)
+    finally:
+        orc.set_flavour(0)
+    assert np.array_equal(bits(o_rays["dist"]), bits(r_rays["dist"])) and np.array_equal(o_rays["triID"], r_rays["triID"])
+    assert np.array_equal(o_counts, r_counts) and r_counts.sum() > 0.3 * rays.size
+    c = pkg.capi.Ctx(0)
+    try:
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        c.resize_rays(rays.size)
+        c.set_record_hits(True)
+        c.set_flavour(2)
+        c.reset(False)
+        c.write_rays(rays)
+        c.extend(rays.size)
+        c.sync()
+        got = c.read_rays(0, rays.size)
+        assert np.array_equal(bits(got["dist"]), bits(r_rays["dist"])), int((bits(got["dist"]) != bits(r_rays["dist"])).sum())
+        assert np.array_equal(got["triID"], r_rays["triID"])
+        assert np.array_equal(c.read_counts(), r_counts)
+    finally:
+        c.close()
+
+
 def test_reference_generate_built_with_its_own_flags(ref, orc, oscene, oroute):
     """generate.cl with the reference's own flags on this GPU: reported against the strict build of the same source
     (fast-math may re-associate the f32 seed sum of generate.cl:13).  Nothing of the product depends on it:
