@@ -9,6 +9,9 @@
 //            [--dump dose.f32 | dose.npy]   raw little-endian f32[T] or NumPy .npy (by extension)
 //            [--ply heatmap.ply]            the room with per-triangle heat-map colours
 //                                           (dosageToColor output; what the reference shows in GL)
+//            [--flavour 0|1|2]              arithmetic of extend (include/uvrt.h uvrt_set_flavour): 0 strict (default), 1 the fused
+//                                           forms of the reference's strict build on gfx950, 2 what the reference's OWN build
+//                                           flags (-cl-fast-relaxed-math, template.cpp:1192) compute on gfx950 (+11 %)
 //            [--batch K]                    trace K iterations per batch (RayTracer::ComputeIterationsBatched:
 //                                           all launches first, accumulate + Shade replayed; same dose bits)
 //            [--gpus N]                     one process, N contexts: every launch split by global-id range
@@ -31,7 +34,7 @@ int main(int argc, char** argv)
 {
     std::string room, routeDir = "positions/", route = "route", dump, saveRoute, ply;
     long long photons = -1;
-    int iterations = -1, lamps = -1, device = 0, gpus = 1, batch = 0;
+    int iterations = -1, lamps = -1, device = 0, gpus = 1, batch = 0, flavour = 0;
     bool calibrate = false;
     float calP = 2909.0f, calH = 0.8f, calD = 1.0f;   // userinterface.cpp:107-109 defaults
     ViewMode view = dosage;
@@ -46,6 +49,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--device")) { need(1); device = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--gpus")) { need(1); gpus = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--batch")) { need(1); batch = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--flavour")) { need(1); flavour = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--dump")) { need(1); dump = argv[++i]; }
         else if (!strcmp(argv[i], "--ply")) { need(1); ply = argv[++i]; }
         else if (!strcmp(argv[i], "--save-route")) { need(1); saveRoute = argv[++i]; }
@@ -108,6 +112,7 @@ int main(int argc, char** argv)
         }
     }
     for (size_t r = 0; r < group.size(); ++r) {
+        if (uvrt_set_flavour(group[r]->ctx, flavour) != UVRT_OK) { fprintf(stderr, "--flavour: %s\n", uvrt_last_error()); return 2; }
         group[r]->ResetDosageMap();                          // userinterface.cpp:247-251
         group[r]->viewMode = view;
         if (gpus > 1) group[r]->SetRayRange((int)r, gpus);

@@ -58,3 +58,28 @@ def test_cli_sharded_and_batched_runs_give_the_same_dose(tmp_path):
         assert np.array_equal(outs[tag][0], outs["plain"][0]), tag
     assert outs["plain"][1].count("Progress: ") == 4 and outs["batch"][1].count("Progress: ") == 2
     assert "Sharding every launch over 3 contexts" in outs["gpus"][1] and outs["plain"][0].any()
+
+
+def test_cli_flavour_option(tmp_path, orc, oscene, oroute):
+    """uvrt_cli --flavour 2: the headless Tick loop in the arithmetic of the reference's own build flags (uvrt_set_flavour 2);
+    the dose equals the oracle's in that flavour (v_rcp_f32 through the table read from this GPU) bit for bit, --flavour 1 equals
+    the oracle in flavour 1, and a flavour that does not exist is refused."""
+    base = [CLI, "--room", GLB, "--route-dir", GOLDEN, "--route", "lange_route", "--lamps", "2", "--photons", "200000",
+            "--iterations", "2"]
+    flavours = [1] + ([2] if orc.refgpu() is not None else [])
+    for fl in flavours:
+        f = tmp_path / ("dose_f%d.f32" % fl)
+        out = subprocess.run(base + ["--flavour", str(fl), "--dump", str(f)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        orc.set_flavour(fl)
+        try:
+            comp = orc.Computation(oscene, oroute["lamps"][:2], 200000, oroute["lightHeight"], oroute["lightLength"],
+                                   oroute["lightIntensity"])
+            comp.reset()
+            comp.iteration(); comp.iteration()
+            ref = comp.dose()
+        finally:
+            orc.set_flavour(0)
+        assert np.array_equal(np.fromfile(f, dtype="<u4"), ref.view(np.uint32)), fl
+    out = subprocess.run(base + ["--flavour", "7"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "0, 1 or 2" in out.stderr
