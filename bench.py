@@ -698,6 +698,9 @@ def main():
                 # five positions next to lamp 1 of the route, none of them seen before (and none a lamp of the route, whose own
                 # cold figure follows below): each first computation is a cold start; the median guards against a one-off
                 base = all_lamps[1]
+                for _ in range(3):          # the legs above end with CPU work (the oracle): bring the GPU's clocks back up first
+                    headline()
+                sync_all()
                 colds = []
                 for k in range(1, 6):
                     configure([(base[0] + 0.015625 * k, base[1] - 0.015625 * k, base[2])], args.photons, args.waves)
