@@ -99,6 +99,7 @@ int uvrt_create(int device_id, uvrt_ctx** out)
 #ifdef UVRT_DEV_VARIANTS
     if (const char* e = getenv("UVRT_PROBE_SKIP_GENERATE")) c->probe_skip_generate = atoi(e);
 #endif
+    if (const char* e = getenv("UVRT_DRAIN_MERGE")) c->drain_merge = atoi(e) != 0;      // developer knob
     if (const char* e = getenv("UVRT_BATCH_LANES")) { const int v = atoi(e); if (v >= 1 && v <= uvrt_ctx::MAXL - 1) c->batch_lanes = v; }
     if (const char* e = getenv("UVRT_COMM_RESERVE_CUS")) { const int v = atoi(e); if (v >= 0 && v <= 64 && v % 8 == 0) c->comm_reserve_knob = v; }
     if (const char* e = getenv("UVRT_HOT_SAMPLE")) { const int v = atoi(e); if (v >= 256 && v <= (1 << 20)) c->hot_sample = v; }

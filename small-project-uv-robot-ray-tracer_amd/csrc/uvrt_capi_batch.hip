@@ -206,6 +206,7 @@ int uvrt_trace_batch(uvrt_ctx* c, const float* lamps, float light_length, int32_
             p.recs = c->b_recs[g].p;
             p.perm = gperm[g];
             p.recs_prepared = 1;
+            p.drain_merge = c->drain_merge;
             p.refill_min = variant_refill_min(c->variant, (size_t)c->npairs + (size_t)c->T);
             p.plane_batches = (uint32_t)(n_pad / 64);
             p.plane_n = (uint32_t)n;

@@ -333,6 +333,7 @@ int uvrt_extend(uvrt_ctx* c, int64_t n)
     // small kernels around it (generate, accumulate, replay) run at once instead of queueing behind persistent waves
     // (profiles/r02/r02_experiments.txt); with four launch lanes 4 per CU
     const int per_cu_default = (c->cur_pipelined && c->nlanes >= 4) ? 4 : c->cur_pipelined ? 7 : 8;
+    p.drain_merge = c->drain_merge;
     if (!launch_extend6(p, variant_code6(c->variant), variant_per_cu(c->variant, per_cu_default), ls))
         return fail(UVRT_ERR_INVALID, "uvrt_extend: variant %d needs a larger overflow-stack buffer than the context holds", c->variant);
     HIP_TRY(hipGetLastError());

@@ -83,6 +83,7 @@ struct uvrt_ctx {
     DevBuf ovf_stack;                          // traversal-stack entries 8..31 of every thread of the persistent grid
     bool recs_valid = false;                   // recs[0, npairs) prepared for the lamp (recs_ox, recs_oz)
     float recs_ox = 0, recs_oz = 0;
+    bool drain_merge = true;                   // k_extend6's workgroups pool the last rays of their waves (ExtendParams::drain_merge; developer knob UVRT_DRAIN_MERGE=0)
     bool scene_force_exact = false;            // a node bound too tiny / too large for the reciprocal shortcuts
     int32_t hist_bins = 0;
     int64_t last_n = -1;

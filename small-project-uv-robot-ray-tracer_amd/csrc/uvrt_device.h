@@ -198,6 +198,7 @@ struct ExtendParams {
     int32_t num_cus;         // compute units of the device (persistent grids are sized from it)
     uint32_t top_pairs;      // pair records [0, top_pairs) = the tree levels cached in LDS (<= TOP6_MAX)
     int32_t force_exact;     // scene or lamp position outside the fast path's proof conditions
+    int32_t drain_merge;     // k_extend6: the four waves of a workgroup pool the last rays of their drains in one wave (merge6)
     int32_t flavour;         // 0 strict (canonical), 1 "ocl-amd" fused cross/dot in the triangle test
     const uint32_t* order;   // [n] trace slot -> local ray index, or nullptr (identity)
     uint2* hits;             // [n] by local ray index: (dist bits, triID), or nullptr

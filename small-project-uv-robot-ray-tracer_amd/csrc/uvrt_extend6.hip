@@ -109,7 +109,7 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
         const uint32_t nearer = sw ? r1 : r0, farther = sw ? r0 : r1;
         if (h0 & h1) {
             if (L.sp < PS6) asm volatile("ds_write_b32 %0, %1 offset:1024" : : "v"(sa), "v"(farther) : "memory");
-            else if (L.sp < MAXS6) ovf_ptr(p)[L.sp - PS6] = farther;
+            else if (L.sp < MAXS6) ovf_ptr(p, stack_base)[L.sp - PS6] = farther;
             else *p.error_flag = 1u;
             L.sp = L.sp < MAXS6 ? L.sp + 1 : L.sp;
         }
@@ -134,7 +134,7 @@ __device__ __forceinline__ void step6(Lane6& L, const ExtendParams& p, uint32_t 
     }
     if (need_pop) {
         uint32_t popped = spec_top;                        // REF_DONE when the stack is empty
-        if (L.sp > PS6) popped = ovf_ptr(p)[L.sp - 1 - PS6];
+        if (L.sp > PS6) popped = ovf_ptr(p, stack_base)[L.sp - 1 - PS6];
         L.cur = popped;
         L.sp = (int)__builtin_elementwise_sub_sat((uint32_t)L.sp, 1u);
     }
@@ -404,7 +404,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "s_mov_b64 exec, %[m3]\n\t" \
         "v_bfe_u32 v58, %[cur], 27, 4\n\t" \
         "v_cmp_ne_u32_e64 %[m4], 1, v58\n\t" \
-        "s_mov_b64 exec, %[full]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
         "s_cmp_lg_u64 %[m4], 0\n\t" \
         "s_cbranch_scc1 8f\n\t" \
         "3:\n\t" \
@@ -426,13 +426,13 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "global_load_dwordx4 v[44:47], v53, %[rb] offset:16\n\t" \
         "global_load_dwordx4 v[48:51], v53, %[rb] offset:32\n\t" \
         "global_load_dwordx4 v[52:55], v53, %[rb] offset:48\n\t" \
-        "s_mov_b64 exec, %[full]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
         "s_cmp_eq_u64 %[m3], 0\n\t" \
         "s_cbranch_scc1 4f\n\t" \
         "s_mov_b64 exec, %[m3]\n\t" \
         TRI \
-        "s_mov_b64 exec, %[full]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
         "4:\n\t" \
         "s_cmp_eq_u64 %[m0], 0\n\t" \
         "s_cbranch_scc1 5f\n\t" \
@@ -474,13 +474,13 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         "s_or_b64 exec, %[m4], %[m3]\n\t" \
         "v_mov_b32 %[cur], v56\n\t" \
         "v_sub_u32 %[sp], %[sp], 1 clamp\n\t" \
-        "s_mov_b64 exec, %[full]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
         "s_branch 1b\n\t" \
         "5:\n\t" \
         "s_mov_b64 exec, %[m3]\n\t" \
         "v_mov_b32 %[cur], v56\n\t" \
         "v_sub_u32 %[sp], %[sp], 1 clamp\n\t" \
-        "s_mov_b64 exec, %[full]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
         "s_branch 1b\n\t" \
         "7:\n\t" \
         "s_mov_b32 %[code], 1\n\t" \
@@ -493,7 +493,7 @@ __device__ __forceinline__ void step7(Lane6& L, const ExtendParams& p, uint32_t 
         : [cur] "+v"(L.cur), [sp] "+v"(L.sp), [dist] "+v"(dist), [tri] "+v"(L.triID), [km] "+s"(km), [code] "=&s"(code), \
           [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4) \
         : [px] "v"(L.px), [py] "v"(L.py), [pz] "v"(L.pz), [po] "v"(L.po), [dx] "v"(L.px.x), [dy] "v"(L.py.x), [dz] "v"(L.pz.x), \
-          [oy] "v"(oy), [sb] "v"(stack_base), [tb] "s"(__builtin_amdgcn_readfirstlane(top_base)), [full] "s"(full), [rb] "s"(p.recs), [spec] "s"(special_mask), \
+          [oy] "v"(oy), [sb] "v"(stack_base), [tb] "s"(__builtin_amdgcn_readfirstlane(top_base)), [rb] "s"(p.recs), [spec] "s"(special_mask), \
           [tp] "s"(top_pairs), [amin] "s"(active_min), [ox] "s"(p.ox), [oz] "s"(p.oz) \
         : "memory", "scc", "vcc", R7_CLOBBERS
 
@@ -511,6 +511,7 @@ __device__ __forceinline__ int run7(Lane6& L, const ExtendParams& p, uint32_t st
     float dist = L.po.y;
     const float oy = L.po.x;
     static_assert(PS6 == 8, "run7 compares the stack pointer with the literal PS6 - 1");
+    (void)full;      // the loop's exec mask is all 64 lanes (full workgroups): the stream writes it as the literal -1, one register pair less
     if constexpr (FL == 2)
         asm volatile(R7_BODY(R7_TRI(R7_CROSS_OCL, R7_DOT_OCL, R7_NEWTON_NONE, R7_GO_A_SHIPPED, R7_GO_01_SHIPPED), R7_SLABS_SHIPPED) R7_OPERANDS);
     else if constexpr (FL == 1)
@@ -535,12 +536,88 @@ __device__ __forceinline__ bool outside_proof_conditions(float4 rec)
     return worst > one - lo || (uo != 0u && uo - ylo > yhi - ylo);
 }
 
+// The drain of a wave's last rays (its share of the launch is handed out, fewer and fewer lanes hold a ray, every trip still costs
+// a full trip) is the dearest part of a launch: 25 % of the trips of a 2 M-ray launch.  Once a wave is down to MERGE6_AT rays it
+// stops and waits for the other three waves of its workgroup to get there; then all four write their rays into LDS and wave 0 goes
+// on with all of them (<= 64) while the others leave: one wave's trips instead of four for the rest of the drain.
+//   * a ray keeps the LDS stack rows (and the overflow rows) of the lane that started it: `stack_base` travels with the ray;
+//   * the exchange area is the tail of the record cache (nobody traverses between the two barriers; afterwards wave 0 treats
+//     only the first TOP6_KEEP records as cached); the four counts sit in the waves' own stack sentinels for the moment;
+//   * every wave passes here exactly once (any wave's drain ends at zero rays): the barriers match by construction.
+// Which lane finishes a ray changes nothing it deposits.  Returns whether this wave goes on.
+#ifndef UVRT_MERGE6_AT
+#define UVRT_MERGE6_AT 16
+#endif
+constexpr uint32_t MERGE6_AT = UVRT_MERGE6_AT, MERGE6_FIELDS = 14;
+static_assert(4 * MERGE6_AT <= 64, "the rays of four waves must fit one");
+constexpr uint32_t TOP6_KEEP = TOP6_MAX + 1 - (MERGE6_FIELDS * 64 * 4 + TOP6_STRIDE - 1) / TOP6_STRIDE;      // 116 records stay cached
+// ints from a wave's replica to the plane of a lane's ray (bit 31 of that register: the ray needs the exact step, see k_extend6)
+constexpr uint32_t PLANE_OFF6 = 0x7FFFFFFFu, SPECIAL6 = 0x80000000u;
+template <bool RECORD>
+__device__ __forceinline__ bool merge6(Lane6& L, const ExtendParams& p, int32_t* my_counts, uint32_t& plane_off, uint32_t& stack_base,
+                                       uint32_t& slot, bool& live, uint32_t* row0, uint32_t* xch)
+{
+    // (few scalars at a time: the kernel's long-lived ones leave little room, and what does not fit is spilled for the whole loop)
+    if (L.cur == REF_DONE) {        // results of the rays these lanes finished since the last refill (extend.cl:94-98)
+        if (RECORD && live && p.hits) {
+            const uint32_t li = p.order ? p.order[slot] : slot;
+            p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
+        }
+        if (L.po.y != 1e30f) atomicAdd(&my_counts[(plane_off & PLANE_OFF6) + L.triID], 1);
+    }
+    // the wave's number in its workgroup comes from the lane's own stack rows (not yet anybody else's; threadIdx.x is not kept)
+    {
+        const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(L.cur != REF_DONE));
+        if (lane_now() == 0u) row0[(stack_base >> 2) & 192u] = cnt;
+    }
+    __syncthreads();
+    if (L.cur != REF_DONE) {
+        // slot = rays of the waves before this one + the lane's rank among the wave's rays (exec = those lanes here)
+        const uint32_t wv = (stack_base >> 8) & 3u;
+        uint32_t s = lane_rank_in_exec();
+        if (wv > 0u) s += row0[0];
+        if (wv > 1u) s += row0[64];
+        if (wv > 2u) s += row0[128];
+        uint32_t* x = xch + s;
+        x[0 * 64] = __float_as_uint(L.px.x); x[1 * 64] = __float_as_uint(L.px.y);
+        x[2 * 64] = __float_as_uint(L.py.x); x[3 * 64] = __float_as_uint(L.py.y);
+        x[4 * 64] = __float_as_uint(L.pz.x); x[5 * 64] = __float_as_uint(L.pz.y);
+        x[6 * 64] = __float_as_uint(L.po.x); x[7 * 64] = __float_as_uint(L.po.y);
+        x[8 * 64] = L.triID; x[9 * 64] = L.cur; x[10 * 64] = (uint32_t)L.sp; x[11 * 64] = plane_off; x[12 * 64] = stack_base;
+        if (RECORD) x[13 * 64] = slot;
+    }
+    __syncthreads();
+    // this wave's rays are in the exchange area
+    const bool goes_on = __builtin_amdgcn_readfirstlane((int)((stack_base >> 8) & 3u)) == 0;
+    set_in_place(L.cur, REF_DONE);
+    L.po.y = 1e30f;
+    live = false;
+    if (!goes_on) return false;
+    const uint32_t lane = lane_now();
+    const uint32_t total = row0[0] + row0[64] + row0[128] + row0[192];
+    if (lane < 4u) row0[lane * 64u] = REF_DONE;          // the count words are stack sentinels again
+    if (lane < total) {
+        const uint32_t* x = xch + lane;
+        set_in_place(L.px, __uint_as_float(x[0 * 64]), __uint_as_float(x[1 * 64]));
+        set_in_place(L.py, __uint_as_float(x[2 * 64]), __uint_as_float(x[3 * 64]));
+        set_in_place(L.pz, __uint_as_float(x[4 * 64]), __uint_as_float(x[5 * 64]));
+        set_in_place(L.po, __uint_as_float(x[6 * 64]), __uint_as_float(x[7 * 64]));
+        set_in_place(L.triID, x[8 * 64]);
+        set_in_place(L.sp, (int)x[10 * 64]);
+        set_in_place(plane_off, x[11 * 64]);
+        set_in_place(stack_base, x[12 * 64]);
+        if (RECORD) { slot = x[13 * 64]; live = true; }
+        set_in_place(L.cur, x[9 * 64]);
+    }
+    return true;
+}
+
 template <int LEAFP, bool RECORD, bool TOP, int FL>
 __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
 {
-    __shared__ uint32_t s_stack[PS6 + 1][256];                      // 9 KB: row 0 always holds REF_DONE ("entry -1"), the stack proper follows
+    __shared__ __attribute__((aligned(1024))) uint32_t s_stack[PS6 + 1][256];   // 9 KB: row 0 always holds REF_DONE ("entry -1"), the stack proper follows
     __shared__ float4 s_top[TOP ? (TOP6_MAX + 1) * (TOP6_STRIDE / 16) : 4];          // 11 KB
-    const uint32_t top_pairs = TOP ? (p.top_pairs < TOP6_MAX ? p.top_pairs : TOP6_MAX) : 0u;
+    uint32_t top_pairs = TOP ? (p.top_pairs < TOP6_MAX ? p.top_pairs : TOP6_MAX) : 0u;      // (fewer after the drain merge)
     if (TOP) {
         const float4* src = (const float4*)p.recs;
         for (uint32_t i = threadIdx.x; i < top_pairs * 4u; i += 256u) {
@@ -551,7 +628,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     }
     s_stack[0][threadIdx.x] = REF_DONE;                               // what a pop from an empty stack yields
     // LDS byte address of this lane's stack entry -1 (entry e at + 1024 (e + 1))
-    const uint32_t stack_base = (uint32_t)(uintptr_t)&s_stack[0][threadIdx.x];
+    uint32_t stack_base = (uint32_t)(uintptr_t)&s_stack[0][threadIdx.x];       // (of the ray's first lane: merge6)
     Lane6 L;
     L.px = L.py = L.pz = (v2f){1.f, 1.f};
     L.po = (v2f){0.f, 1e30f};      // dist == 1e30f <=> nothing to deposit
@@ -560,10 +637,12 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     L.sp = 0;
     uint32_t slot = 0;
     bool live = false;             // RECORD: holds a ray whose (dist, triID) has not been written yet
-    unsigned long long special_mask = 0;   // lanes whose ray needs the EXACT step (wave-uniform value)
     int32_t* const my_counts = p.counts + (int64_t)(blockIdx.x % (unsigned)p.count_replicas) * p.count_stride;
     const uint32_t root6 = (p.perm && p.root_ref6 < REF_LEAF_BIT) ? p.perm[p.root_ref6] : p.root_ref6;
-    uint32_t plane_off = 0;        // ints from my_counts to the plane of the ray this lane holds
+    // ints from my_counts to the plane of the ray this lane holds; bit 31: the ray needs the EXACT step (outside the proof
+    // conditions of the packed division) -- the wave's mask of such lanes is a ballot of that bit where it is needed, not a
+    // register pair carried through the loop (the kernel runs at its scalar-register budget)
+    uint32_t plane_off = 0;
     const float plane_inv = p.plane_inv;
 
     // wave w traces the 64-ray batches w, w + W, w + 2W, ...: static ownership, no atomics, and batches
@@ -581,6 +660,9 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
     // refill when this many lanes are idle; once the wave's sequence is exhausted only the all-idle exit is left
     const int refill_c = p.refill_min;      // 1..64 (launch_extend6)
     int refill_at = refill_c;
+    // (cursor == MERGED6 once the wave has been through the workgroup's drain merge (merge6), or from the end of its share on when
+    //  the launch does without: the state costs no register of its own)
+    constexpr uint32_t MERGED6 = 0xFFFFFFFFu;
 #ifdef UVRT_TRIP_STATS     // developer build (tests/tools/trip_stats.sh): where the trips' lanes go
     uint32_t st_trips = 0, st_in = 0, st_leaf = 0, st_wait = 0, st_idle = 0, st_leaftrips = 0, st_drain = 0, st_slow = 0,
              st_refills = 0, st_top = 0, st_d9 = 0, st_d10 = 0, st_d11 = 0, st_d12 = 0;
@@ -606,7 +688,10 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             // every loop-carried scalar whose update depends on them, as divergent and keeps them in vector registers)
             // (two call sites: a select between the two thresholds would drag `cursor` into a vector register)
             int why;
+            const unsigned long long special_mask = FL == 2 ? 0ull : __builtin_amdgcn_ballot_w64((int32_t)plane_off < 0);
             if (cursor < chunk_end) why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 64 - refill_c);
+            // (the wave's share is handed out: stop at MERGE6_AT rays for the merge, afterwards only when all are done)
+            else if (TOP && cursor != MERGED6) why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, (int)MERGE6_AT);
             else why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 0);
             why = __builtin_amdgcn_readfirstlane(why);
             kflag = __builtin_amdgcn_readfirstlane(kflag);
@@ -621,7 +706,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                             const uint32_t li = p.order ? p.order[slot] : slot;
                             p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
                         }
-                        if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);
+                        if (L.po.y != 1e30f) atomicAdd(&my_counts[(plane_off & PLANE_OFF6) + L.triID], 1);
                         live = false;
                         L.po.y = 1e30f;
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
@@ -640,7 +725,6 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                             else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
                         }
                         if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
-                            set_in_place(plane_off, pl * p.plane_stride);
                             const float4 rec = p.rays[my];
                             // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
                             // and never use y); flavour 2: y = v_rcp_f32(d), used by every lane
@@ -653,13 +737,21 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                             set_in_place(L.sp, 0);
                             set_in_place(L.cur, root6);
                             spec = FL != 2 && (outside_proof_conditions(rec) || p.force_exact != 0);
+                            set_in_place(plane_off, pl * p.plane_stride | (spec ? SPECIAL6 : 0u));
                         }
                     }
                     cursor += (uint32_t)nidle;
-                    special_mask = (special_mask & ~idle_mask) | __builtin_amdgcn_ballot_w64(spec);
-                    if (cursor >= chunk_end) refill_at = 64;
+                    if (cursor >= chunk_end) { refill_at = 64; if (!TOP || p.drain_merge == 0) cursor = MERGED6; }
+                } else if (TOP && cursor != MERGED6) {
+                    cursor = MERGED6;
+                    const bool go_on = merge6<RECORD>(L, p, my_counts, plane_off, stack_base, slot, live, &s_stack[0][0],
+                                                      (uint32_t*)&s_top[TOP ? TOP6_KEEP * (TOP6_STRIDE / 16u) : 0u]);
+                    if (!go_on) break;
+                    top_pairs = top_pairs < TOP6_KEEP ? top_pairs : TOP6_KEEP;
+                    continue;
                 }
-                if (cursor >= chunk_end && __builtin_amdgcn_ballot_w64(L.cur != REF_DONE) == 0) break;
+                // (a wave leaves only after the merge: the other waves of its workgroup count on its count)
+                if (cursor == MERGED6 && __builtin_amdgcn_ballot_w64(L.cur != REF_DONE) == 0) break;
                 continue;
             }
             const unsigned long long m_in = __builtin_amdgcn_ballot_w64((int32_t)L.cur >= 0);
@@ -673,8 +765,17 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
         }
     } else
     for (;;) {
+        const unsigned long long special_mask = FL == 2 ? 0ull : __builtin_amdgcn_ballot_w64((int32_t)plane_off < 0);
         const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(L.cur == REF_DONE);
         const int nidle = __popcll(idle_mask);
+        if (TOP && cursor >= chunk_end && cursor != MERGED6 && 64 - nidle <= (int)MERGE6_AT) {
+            cursor = MERGED6;
+            const bool go_on = merge6<RECORD>(L, p, my_counts, plane_off, stack_base, slot, live, &s_stack[0][0],
+                                              (uint32_t*)&s_top[TOP ? TOP6_KEEP * (TOP6_STRIDE / 16u) : 0u]);
+            if (!go_on) break;
+            top_pairs = top_pairs < TOP6_KEEP ? top_pairs : TOP6_KEEP;
+            continue;
+        }
         if (nidle >= refill_at) {
 #ifdef UVRT_TRIP_STATS
             unsigned long long tclk = __builtin_readcyclecounter();
@@ -687,7 +788,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                         const uint32_t li = p.order ? p.order[slot] : slot;
                         p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
                     }
-                    if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);
+                    if (L.po.y != 1e30f) atomicAdd(&my_counts[(plane_off & PLANE_OFF6) + L.triID], 1);
                     live = false;
                     L.po.y = 1e30f;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
@@ -706,7 +807,6 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                         else if ((uint32_t)within >= p.plane_batches) { ++pl; within -= (int32_t)p.plane_batches; }
                     }
                     if (v < chunk_end && my < n32 && (uint32_t)within * 64u + (v & 63u) < p.plane_n) {
-                        set_in_place(plane_off, pl * p.plane_stride);
                         const float4 rec = p.rays[my];
                         // y = RN32(1/d) (rcp_exact: exact for 2^-64 <= |d| < 2^64; other lanes are `spec`
                         // and never use y); flavour 2: y = v_rcp_f32(d), used by every lane
@@ -719,18 +819,18 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
                         set_in_place(L.sp, 0);
                         set_in_place(L.cur, root6);
                         spec = FL != 2 && (outside_proof_conditions(rec) || p.force_exact != 0);
+                        set_in_place(plane_off, pl * p.plane_stride | (spec ? SPECIAL6 : 0u));
                     }
                 }
                 cursor += (uint32_t)nidle;
-                special_mask = (special_mask & ~idle_mask) | __builtin_amdgcn_ballot_w64(spec);
-                if (cursor >= chunk_end) refill_at = 64;
+                if (cursor >= chunk_end) { refill_at = 64; if (!TOP || p.drain_merge == 0) cursor = MERGED6; }
 #ifdef UVRT_TRIP_STATS
                 ++st_refills;
                 { const unsigned long long t1_ = __builtin_readcyclecounter(); clk[3] += (uint32_t)(t1_ - tclk); }
 #endif
             }
             if (__builtin_amdgcn_ballot_w64(L.cur != REF_DONE) == 0) {
-                if (cursor >= chunk_end) break;
+                if (cursor == MERGED6) break;
                 continue;
             }
         }
@@ -806,7 +906,7 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
         const uint32_t li = p.order ? p.order[slot] : slot;
         p.hits[li] = make_uint2(__float_as_uint(L.po.y), L.triID);
     }
-    if (L.po.y != 1e30f) atomicAdd(&my_counts[plane_off + L.triID], 1);   // extend.cl:94-98
+    if (L.po.y != 1e30f) atomicAdd(&my_counts[(plane_off & PLANE_OFF6) + L.triID], 1);   // extend.cl:94-98
 }
 
 // Per-launch node-pair records recs[0, P): the lamp's x and z subtracted from the x / z bounds (the

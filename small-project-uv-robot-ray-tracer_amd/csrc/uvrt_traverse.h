@@ -225,4 +225,28 @@ __device__ __forceinline__ uint32_t* ovf_ptr(const ExtendParams& p)
     return p.ovf_stack + ((size_t)blockIdx.x * 256 + wv * 64 + lane) * (MAXS6 - PS6);
 }
 
+// the lane's number, computed where it is asked for (threadIdx.x, or a mbcnt the compiler can share, would stay live in a vector
+// register from the kernel's entry on -- k_extend6 has none to spare)
+__device__ __forceinline__ uint32_t lane_now()
+{
+    uint32_t lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+
+// the lane's rank among the lanes that are executing (asked for inside a divergent region: no mask to carry there)
+__device__ __forceinline__ uint32_t lane_rank_in_exec()
+{
+    uint32_t r;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, exec_lo, 0\n\tv_mbcnt_hi_u32_b32 %0, exec_hi, %0" : "=v"(r));
+    return r;
+}
+
+// The same for a ray that may have moved to another lane of its workgroup (k_extend6's drain merge): the rows belong to the lane whose
+// LDS stack the ray uses.  stack_base = LDS address of that lane's entry -1; the stack array is aligned to its 1 KB rows.
+__device__ __forceinline__ uint32_t* ovf_ptr(const ExtendParams& p, uint32_t stack_base)
+{
+    return p.ovf_stack + ((size_t)blockIdx.x * 256 + ((stack_base >> 2) & 255u)) * (MAXS6 - PS6);
+}
+
 }  // namespace uvrt

@@ -82,6 +82,41 @@ def test_extend_hits_and_counts_bit_exact(ctx, orc, oscene, oroute, sort_bits):
     ctx.set_record_hits(False)
 
 
+@pytest.mark.parametrize("merge", ["0", "1"])
+@pytest.mark.parametrize("flavour", [0, 2])
+def test_drain_merge_changes_nothing(pkg, orc, oscene, oroute, monkeypatch, merge, flavour):
+    """k_extend6's workgroups pool the last rays of their four waves in one wave (merge6; by default only when launches can
+    overlap).  Forced on and off (UVRT_DRAIN_MERGE, read at uvrt_create): per-ray (dist, triID) and counts are the oracle's either
+    way -- launches of less than one batch per wave (waves without rays meet the barriers too), ragged sizes, several batches
+    per wave, with and without hit records."""
+    monkeypatch.setenv("UVRT_DRAIN_MERGE", merge)
+    c = pkg.capi.Ctx(0)
+    try:
+        c.set_scene(oscene.tris, oscene.nodes, oscene.triIdx)
+        c.set_flavour(flavour)
+        lp = lamp_pos(orc, oscene, oroute, 5)
+        orc.set_flavour(flavour)
+        for n, rec in ((1, True), (200000, True), (200000, False), (458753, True), (1500001, False)):
+            c.set_record_hits(rec)
+            c.resize_rays(n)
+            c.reset(False)
+            c.seed = 0
+            c.generate(lp, oroute["lightLength"], 0, n)
+            c.extend(n)
+            c.sync()
+            rays, _ = orc.generate(0, n, lp, oroute["lightLength"], 0)
+            temp = np.zeros(oscene.T, dtype=np.int32)
+            orc.extend(temp, oscene.tris, rays, oscene.nodes, oscene.triIdx)
+            assert np.array_equal(c.read_counts(), temp), (n, rec)
+            if rec:
+                got = c.read_rays(0, n)
+                assert np.array_equal(bits(got["dist"]), bits(rays["dist"])), n
+                assert np.array_equal(got["triID"], rays["triID"]), n
+    finally:
+        orc.set_flavour(0)
+        c.close()
+
+
 @pytest.mark.parametrize("variant", [0, 400, 401, 402, 403, 404, 405, 406, 407, 411, 421, 431, 441, 500, 501, 505, 601, 702, 801])
 def test_every_extend_variant_is_bit_exact(pkg, ctx, ctx_dev, orc, oscene, oroute, variant):
     """All kernel knob settings (leaf period, LDS top cache on / off, 2-16 workgroups per CU, refill
