@@ -689,10 +689,17 @@ __global__ __launch_bounds__(256, 8) void k_extend6(ExtendParams p)
             // (two call sites: a select between the two thresholds would drag `cursor` into a vector register)
             int why;
             const unsigned long long special_mask = FL == 2 ? 0ull : __builtin_amdgcn_ballot_w64((int32_t)plane_off < 0);
-            if (cursor < chunk_end) why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 64 - refill_c);
-            // (the wave's share is handed out: stop at MERGE6_AT rays for the merge, afterwards only when all are done)
-            else if (TOP && cursor != MERGED6) why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, (int)MERGE6_AT);
-            else why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, 0);
+            // rays at which the stream comes back: enough idle lanes for a refill; the wave's share handed out: MERGE6_AT for the
+            // drain merge, afterwards none.  ONE call site (each one gets its own registers for the lane state, and the loop then
+            // copies it at every join), so the threshold is a value -- computed with scalar instructions spelled out: a C++ select
+            // on `cursor` drags it into a vector register.
+            int thr;
+            asm("s_cmp_eq_u32 %[c], -1\n\t"
+                "s_cselect_b32 %[t], 0, %[k]\n\t"
+                "s_cmp_lt_u32 %[c], %[e]\n\t"
+                "s_cselect_b32 %[t], %[a], %[t]"
+                : [t] "=&s"(thr) : [c] "s"(cursor), [e] "s"(chunk_end), [a] "s"(64 - refill_c), [k] "n"(TOP ? MERGE6_AT : 0u) : "scc");
+            why = run7<FL, LEAFP>(L, p, stack_base, top_base, top_pairs, special_mask, kflag, full, thr);
             why = __builtin_amdgcn_readfirstlane(why);
             kflag = __builtin_amdgcn_readfirstlane(kflag);
             if (why == 1) {
