@@ -550,7 +550,7 @@ __device__ __forceinline__ bool outside_proof_conditions(float4 rec)
 #endif
 constexpr uint32_t MERGE6_AT = UVRT_MERGE6_AT, MERGE6_FIELDS = 14;
 static_assert(4 * MERGE6_AT <= 64, "the rays of four waves must fit one");
-constexpr uint32_t TOP6_KEEP = TOP6_MAX + 1 - (MERGE6_FIELDS * 64 * 4 + TOP6_STRIDE - 1) / TOP6_STRIDE;      // 116 records stay cached
+constexpr uint32_t TOP6_KEEP = TOP6_MAX + 1 - (MERGE6_FIELDS * 64 * 4 + TOP6_STRIDE - 1) / TOP6_STRIDE;      // 120 records stay cached
 // ints from a wave's replica to the plane of a lane's ray (bit 31 of that register: the ray needs the exact step, see k_extend6)
 constexpr uint32_t PLANE_OFF6 = 0x7FFFFFFFu, SPECIAL6 = 0x80000000u;
 template <bool RECORD>
